@@ -1,0 +1,266 @@
+"""ctypes binding of libconjugate_gradient_gpu.so (see include/conjugate_gradient_gpu.h).
+
+Function names, argument order and meaning follow the reference's Julia wrappers
+(/root/reference/src/main.jl:16-58), so a call site reads like the reference's own.
+Device vectors are passed as integer addresses (e.g. torch_tensor.data_ptr()).
+"""
+import ctypes as C
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libconjugate_gradient_gpu.so")
+
+EXPORTS = [
+    # part 1: the reference's symbols
+    "conjugate_gradient_gpu", "inner_product_gpu", "neighbour_index_gpu", "strong_scaling",
+    "time_cpu_laplace", "add_jl", "laplace_gpu_jl",
+    # part 2: additions
+    "cg_allocate_field", "cg_free_field", "conjugate_gradient_gpu_ex", "preconditioned_cg_gpu",
+    "cg_laplace_device", "cg_fill_uniform", "cg_u01_host",
+    "cg_solver_buffer_len", "cg_solver_ghost_offset", "cg_solver_plane", "cg_solver_create",
+    "cg_solver_destroy", "cg_solver_engine", "cg_solver_blocks", "cg_solver_begin", "cg_solver_iterate",
+    "cg_solver_finish", "cg_solver_sync", "cg_solver_time_kernels", "cg_solver_begin_local",
+    "cg_solver_reduce", "cg_solver_bind_sums", "cg_solver_init_state", "cg_solver_add_iterations",
+    "cg_solver_kernel_A", "cg_solver_kernel_B", "cg_solver_r", "cg_solver_p",
+]
+
+
+class SolverDesc(C.Structure):
+    _fields_ = [("d", C.c_int), ("extents", C.c_uint * 32), ("index_mode", C.c_int),
+                ("has_lo", C.c_int), ("has_hi", C.c_int), ("stream", C.c_void_p),
+                ("r_buf", C.c_void_p), ("p0_buf", C.c_void_p), ("p1_buf", C.c_void_p),
+                ("engine", C.c_int)]
+
+
+def build_library():
+    """Compile the HIP library in-tree (hipcc cross-compiles for gfx950 without a GPU)."""
+    subprocess.run(["make", "-s", "-j8", "-C", PKG_DIR], check=True)
+    return LIB_PATH
+
+
+def _ptr(p):
+    return C.c_void_p(int(p) if p else None)
+
+
+class Library:
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `make -C {PKG_DIR}` "
+                "(there is no fallback implementation)")
+        self.path = path
+        self.c = C.CDLL(path)
+        c = self.c
+        fp, vp, u32, i32 = C.c_void_p, C.c_void_p, C.c_uint, C.c_int
+        c.conjugate_gradient_gpu.argtypes = [fp, fp, i32, i32]
+        c.conjugate_gradient_gpu.restype = C.c_float
+        c.inner_product_gpu.argtypes = [fp, fp, u32]
+        c.inner_product_gpu.restype = C.c_float
+        c.neighbour_index_gpu.argtypes = [u32, i32, i32, u32, u32, u32, i32]
+        c.neighbour_index_gpu.restype = u32
+        c.strong_scaling.argtypes = [i32] * 5
+        c.strong_scaling.restype = C.c_float
+        c.time_cpu_laplace.argtypes = [i32] * 3
+        c.time_cpu_laplace.restype = C.c_float
+        c.add_jl.argtypes = [fp, fp, i32, i32]
+        c.add_jl.restype = None
+        c.laplace_gpu_jl.argtypes = [fp, fp, C.c_float, i32, i32, i32, u32, u32, u32]
+        c.laplace_gpu_jl.restype = None
+        c.cg_allocate_field.argtypes = [i32]
+        c.cg_allocate_field.restype = C.c_void_p
+        c.cg_free_field.argtypes = [fp]
+        c.cg_free_field.restype = None
+        c.conjugate_gradient_gpu_ex.argtypes = [fp, fp, i32, i32, i32, i32, C.c_double, i32, i32,
+                                                C.POINTER(C.c_int), vp, i32]
+        c.conjugate_gradient_gpu_ex.restype = C.c_float
+        c.preconditioned_cg_gpu.argtypes = [vp, vp, i32, i32, vp, i32, i32]
+        c.preconditioned_cg_gpu.restype = i32
+        c.cg_laplace_device.argtypes = [fp, fp, i32, i32, i32, vp]
+        c.cg_laplace_device.restype = None
+        c.cg_fill_uniform.argtypes = [fp, C.c_ulonglong, u32]
+        c.cg_fill_uniform.restype = None
+        c.cg_u01_host.argtypes = [u32, C.c_ulonglong]
+        c.cg_u01_host.restype = C.c_float
+        dp = C.POINTER(SolverDesc)
+        for f in ("cg_solver_buffer_len", "cg_solver_ghost_offset", "cg_solver_plane"):
+            getattr(c, f).argtypes = [dp]
+            getattr(c, f).restype = C.c_size_t
+        c.cg_solver_create.argtypes = [dp]
+        c.cg_solver_create.restype = C.c_void_p
+        c.cg_solver_destroy.argtypes = [vp]
+        c.cg_solver_destroy.restype = None
+        for f in ("cg_solver_engine", "cg_solver_blocks"):
+            getattr(c, f).argtypes = [vp]
+            getattr(c, f).restype = i32
+        c.cg_solver_begin.argtypes = [vp, fp, fp, C.c_double, i32]
+        c.cg_solver_begin.restype = None
+        c.cg_solver_iterate.argtypes = [vp, i32, i32]
+        c.cg_solver_iterate.restype = None
+        c.cg_solver_finish.argtypes = [vp, C.POINTER(C.c_float), vp, i32]
+        c.cg_solver_finish.restype = i32
+        c.cg_solver_sync.argtypes = [vp]
+        c.cg_solver_sync.restype = None
+        c.cg_solver_time_kernels.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        c.cg_solver_time_kernels.restype = None
+        c.cg_solver_begin_local.argtypes = [vp, fp, fp]
+        c.cg_solver_begin_local.restype = None
+        c.cg_solver_reduce.argtypes = [vp, i32, vp]
+        c.cg_solver_reduce.restype = None
+        c.cg_solver_bind_sums.argtypes = [vp, vp, vp]
+        c.cg_solver_bind_sums.restype = None
+        c.cg_solver_init_state.argtypes = [vp, C.c_double, i32, i32]
+        c.cg_solver_init_state.restype = None
+        c.cg_solver_add_iterations.argtypes = [vp, i32]
+        c.cg_solver_add_iterations.restype = None
+        for f in ("cg_solver_kernel_A", "cg_solver_kernel_B"):
+            getattr(c, f).argtypes = [vp]
+            getattr(c, f).restype = None
+        c.cg_solver_r.argtypes = [vp]
+        c.cg_solver_r.restype = C.c_void_p
+        c.cg_solver_p.argtypes = [vp, i32]
+        c.cg_solver_p.restype = C.c_void_p
+
+    # ---- the reference's entry points (main.jl:16-58) --------------------------------
+    def conjugate_gradient_gpu(self, b, x, L, d):
+        return self.c.conjugate_gradient_gpu(_ptr(b), _ptr(x), L, d)
+
+    def inner_product_gpu(self, v, w, N):
+        return self.c.inner_product_gpu(_ptr(v), _ptr(w), N)
+
+    def neighbour_index_gpu(self, ind, direction, amount, L, d, N, index_mode):
+        return self.c.neighbour_index_gpu(ind, direction, amount, L, d, N, index_mode)
+
+    def strong_scaling(self, nblocks, threads_per_block, N, L, d):
+        return self.c.strong_scaling(nblocks, threads_per_block, N, L, d)
+
+    def time_cpu_laplace(self, N, L, d):
+        return self.c.time_cpu_laplace(N, L, d)
+
+    def add_jl(self, A, B, blocks, threads):
+        self.c.add_jl(_ptr(A), _ptr(B), blocks, threads)
+
+    def laplace_gpu_jl(self, ddf, u, dx, d, L, N, index_mode, blocks, threads):
+        self.c.laplace_gpu_jl(_ptr(ddf), _ptr(u), dx, d, L, N, index_mode, blocks, threads)
+
+    # ---- additions -------------------------------------------------------------------
+    def conjugate_gradient_gpu_ex(self, b, x, L, d, index_mode=0, maxit=200, rel=1e-6, lagged=1,
+                                  verbose=0, hist_len=0):
+        """Returns (residue, iterations, history)."""
+        it = C.c_int(0)
+        hist = (C.c_float * max(hist_len, 1))()
+        res = self.c.conjugate_gradient_gpu_ex(_ptr(b), _ptr(x), L, d, index_mode, maxit, rel, lagged,
+                                               verbose, C.byref(it), C.cast(hist, C.c_void_p) if hist_len else None,
+                                               hist_len)
+        return res, it.value, list(hist)[:min(hist_len, it.value)]
+
+    def preconditioned_cg_gpu(self, b, x, L, d, verbose=0):
+        """b, x: addresses of N doubles (host or device). Returns (outer_iterations, [inner steps])."""
+        inner = (C.c_int * 1002)()
+        outer = self.c.preconditioned_cg_gpu(_ptr(b), _ptr(x), L, d, C.cast(inner, C.c_void_p), 1002, verbose)
+        return outer, [v for v in inner if v][:outer + 1] if outer else []
+
+    def make_solver(self, extents, index_mode=0, has_lo=0, has_hi=0, stream=None, r_buf=None, p0_buf=None,
+                    p1_buf=None, engine=0):
+        return Solver(self, extents, index_mode, has_lo, has_hi, stream, r_buf, p0_buf, p1_buf, engine)
+
+    def desc(self, extents, index_mode=0, has_lo=0, has_hi=0, stream=None, r_buf=None, p0_buf=None, p1_buf=None,
+             engine=0):
+        d = SolverDesc()
+        d.d = len(extents)
+        for k, e in enumerate(extents):
+            d.extents[k] = int(e)
+        d.index_mode, d.has_lo, d.has_hi = index_mode, int(has_lo), int(has_hi)
+        d.stream = int(stream) if stream else None
+        d.r_buf = int(r_buf) if r_buf else None
+        d.p0_buf = int(p0_buf) if p0_buf else None
+        d.p1_buf = int(p1_buf) if p1_buf else None
+        d.engine = engine
+        return d
+
+
+class Solver:
+    """The fused two-kernel CG iteration on device-resident vectors (cg_solver_* entry points)."""
+
+    def __init__(self, lib, extents, index_mode, has_lo, has_hi, stream, r_buf, p0_buf, p1_buf, engine):
+        self.lib = lib
+        self.extents = [int(e) for e in extents]
+        self._desc = lib.desc(extents, index_mode, has_lo, has_hi, stream, r_buf, p0_buf, p1_buf, engine)
+        self.h = lib.c.cg_solver_create(C.byref(self._desc))
+        if not self.h:
+            raise RuntimeError("cg_solver_create failed")
+        self.N = 1
+        for e in self.extents:
+            self.N *= e
+
+    def close(self):
+        if self.h:
+            self.lib.c.cg_solver_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def engine(self):
+        return self.lib.c.cg_solver_engine(self.h)
+
+    @property
+    def blocks(self):
+        return self.lib.c.cg_solver_blocks(self.h)
+
+    def begin(self, b, x, rel=1e-6, lagged=1):
+        self.lib.c.cg_solver_begin(self.h, _ptr(b), _ptr(x), rel, lagged)
+
+    def iterate(self, n, use_graph=True):
+        self.lib.c.cg_solver_iterate(self.h, n, int(use_graph))
+
+    def sync(self):
+        self.lib.c.cg_solver_sync(self.h)
+
+    def finish(self, hist_len=0):
+        res = C.c_float(0)
+        hist = (C.c_float * max(hist_len, 1))()
+        n = self.lib.c.cg_solver_finish(self.h, C.byref(res), C.cast(hist, C.c_void_p) if hist_len else None, hist_len)
+        return n, res.value, list(hist)[:min(hist_len, n)]
+
+    def time_kernels(self, n):
+        a, b = C.c_float(0), C.c_float(0)
+        self.lib.c.cg_solver_time_kernels(self.h, n, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    # step interface (slab driver)
+    def begin_local(self, b, x):
+        self.lib.c.cg_solver_begin_local(self.h, _ptr(b), _ptr(x))
+
+    def reduce(self, which, out):
+        self.lib.c.cg_solver_reduce(self.h, which, _ptr(out))
+
+    def bind_sums(self, pAp, rr):
+        self.lib.c.cg_solver_bind_sums(self.h, _ptr(pAp), _ptr(rr))
+
+    def init_state(self, rel, lagged, maxit):
+        self.lib.c.cg_solver_init_state(self.h, rel, lagged, maxit)
+
+    def add_iterations(self, n):
+        self.lib.c.cg_solver_add_iterations(self.h, n)
+
+    def kernel_A(self):
+        self.lib.c.cg_solver_kernel_A(self.h)
+
+    def kernel_B(self):
+        self.lib.c.cg_solver_kernel_B(self.h)
+
+
+_LIB = None
+
+
+def load_library():
+    """The process-wide Library; raises if the shared object has not been built."""
+    global _LIB
+    if _LIB is None:
+        _LIB = Library()
+    return _LIB

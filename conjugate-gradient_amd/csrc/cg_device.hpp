@@ -1,0 +1,572 @@
+// cg_device.hpp -- the CDNA4 (gfx950) kernels of the fused Laplace-CG iteration.
+//
+// One CG iteration of the reference (conjugate-gradient_gpu.cu:349-370) is five
+// kernels, two blocking dot products and three axpy passes.  Here it is two kernels:
+//
+//   kernel A (MODE_A):  p_new = r + beta*p_old            (reference muladd3, :302-308,:363)
+//                       partial sums of  p_new . (A p_new) (laplace_gpu :164-178 + the dot :355)
+//   kernel B (MODE_B):  x += alpha*p ; r -= alpha*(A p)    (muladd :293-299,:356-357)
+//                       partial sums of  r . r             (:359)
+//
+// A p is never stored: kernel B recomputes the stencil from p, which costs no HBM
+// traffic beyond the halo and saves one store and one load of a whole vector.  HBM
+// words per grid point per iteration: A reads r,p_old and writes p_new (3), B reads
+// x,p,r and writes x,r (5).  p is double-buffered (p0/p1, selected by iteration
+// parity) because kernel A recomputes r + beta*p_old at halo points that belong to
+// other workgroups.
+//
+// alpha, beta, the iteration counter and the stop test live on the device
+// (CgState).  Dot products are deterministic: every workgroup writes one double
+// partial; the consumer kernel's wave 0 sums the partials in a fixed order, so all
+// workgroups derive bit-identical scalars and no atomics are used
+// (the reference accumulates with float atomicAdd, :227-228).
+//
+// Two engines implement the same three modes:
+//   k_rows   -- lexicographic layout, 4 points per lane along axis 0 (16-byte
+//               accesses), workgroup marches along axis 1 keeping rows y-1,y,y+1 in
+//               registers, x-neighbours through cross-lane shifts.
+//   k_scalar -- one point per lane; any extent, any d, and the Morton layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "index_map.hpp"
+
+namespace cgamd
+{
+
+constexpr int CG_MAXD = 32;        // scalar engine
+constexpr int CG_ROWS_MAXD = 8;    // rows engine: axes 2..9
+constexpr int CG_MAX_BLOCKS = 2048;
+constexpr int CG_HIST = 1024;      // ring of r.r values, indexed by iteration mod CG_HIST
+
+enum
+{
+  MODE_STENCIL = 0,
+  MODE_A = 1,
+  MODE_B = 2
+};
+enum
+{
+  LAYOUT_LEX = 0,
+  LAYOUT_MORTON = 2
+};
+
+// Iteration control block in device memory.  Kernel A only reads side A and writes
+// side B; kernel B only reads side B and writes side A; so no launch reads a word
+// that the same launch writes.
+struct CgState
+{
+  int itA;   // iteration about to start
+  int doneA; // stop test has fired (sticky)
+  int itB;
+  int doneB;
+  int activeB; // kernel A ran its body for iteration itB
+  int maxit;   // iterations >= maxit pause (not sticky)
+  int lagged;  // 1: test sqrt(rr_{k-1}) as conjugate-gradient_gpu.cu:349,366; 0: test sqrt(rr_k) as cpu.cu:299,317
+  float reltol;
+  float alpha, beta;
+  float pAp;
+  float rr_hist[CG_HIST];
+};
+
+struct VecArgs
+{
+  const float *u; // MODE_STENCIL input
+  float *out;     // MODE_STENCIL output
+  float *x;
+  float *r;
+  float *p0;
+  float *p1;
+  CgState *st;
+  const double *sumA; // p.Ap as nA addends (per-block partials, or 1 all-reduced value)
+  int nA;
+  const double *sumB; // r.r as nB addends
+  int nB;
+  double *part_out; // this launch's per-block partials
+};
+
+struct RowsGeom
+{
+  int d;
+  unsigned n0, n1;
+  unsigned nxc, ty, nstrips;
+  unsigned long long ntiles;
+  unsigned nk[CG_ROWS_MAXD];
+  unsigned long long sk[CG_ROWS_MAXD];
+  int has_lo, has_hi;
+};
+
+struct ScalarGeom
+{
+  int d;
+  unsigned long long N;
+  unsigned n[CG_MAXD];
+  unsigned long long stride[CG_MAXD];
+  unsigned mmask[CG_MAXD];
+  int has_lo, has_hi;
+};
+
+// ---- reductions ----------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v += __shfl_xor(v, o);
+  return v;
+}
+
+// Sum of src[0..n) handed to every thread of the workgroup.  Wave 0 does the work in an
+// order that depends only on n, so every workgroup of every launch shape gets the same bits.
+__device__ __forceinline__ double block_read_sum(const double *__restrict__ src, int n, double *sh)
+{
+  if (threadIdx.x < 64)
+  {
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 64)
+      s += src[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0)
+      sh[0] = s;
+  }
+  __syncthreads();
+  double v = sh[0];
+  __syncthreads();
+  return v;
+}
+
+__device__ __forceinline__ void block_write_partial(float acc, double *__restrict__ part_out, double *sh)
+{
+  double v = wave_sum((double)acc);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0)
+    sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double s = 0;
+    for (int i = 0; i < nw; i++)
+      s += sh[i];
+    part_out[blockIdx.x] = s;
+  }
+}
+
+// ---- iteration control ---------------------------------------------------------------
+
+struct IterCtl
+{
+  bool active;
+  float coef; // beta for kernel A, alpha for kernel B
+  int k;
+};
+
+__device__ __forceinline__ IterCtl prologue_A(const VecArgs &a, double *sh)
+{
+  CgState *st = a.st;
+  const int k = st->itA;
+  const int done = st->doneA;
+  const float rr = (float)block_read_sum(a.sumB, a.nB, sh);
+  const float rr_prev = st->rr_hist[(k + CG_HIST - 1) % CG_HIST];
+  const float rr_test = (st->lagged && k > 0) ? rr_prev : rr;
+  const float residue = (float)sqrt((double)rr_test);
+  const bool conv = done || !(residue > st->reltol);
+  IterCtl c;
+  c.k = k;
+  c.active = !conv && k < st->maxit;
+  c.coef = k > 0 ? rr / rr_prev : 0.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    st->itB = k;
+    st->doneB = conv;
+    st->activeB = c.active;
+    st->rr_hist[k % CG_HIST] = rr;
+    st->beta = c.coef;
+  }
+  return c;
+}
+
+__device__ __forceinline__ IterCtl prologue_B(const VecArgs &a, double *sh)
+{
+  CgState *st = a.st;
+  IterCtl c;
+  c.k = st->itB;
+  c.active = st->activeB != 0;
+  const int done = st->doneB;
+  const float pAp = (float)block_read_sum(a.sumA, a.nA, sh);
+  c.coef = st->rr_hist[c.k % CG_HIST] / pAp;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    st->itA = c.active ? c.k + 1 : c.k;
+    st->doneA = done;
+    if (c.active)
+    {
+      st->alpha = c.coef;
+      st->pAp = pAp;
+    }
+  }
+  return c;
+}
+
+// ---- the stencil input of each mode ----------------------------------------------------
+
+template <int MODE>
+struct Src
+{
+  const float *__restrict__ p;
+  const float *__restrict__ r;
+  float beta;
+  __device__ __forceinline__ float ld1(long long i) const
+  {
+    float v = p[i];
+    if constexpr (MODE == MODE_A)
+      v = fmaf(beta, v, r[i]);
+    return v;
+  }
+  __device__ __forceinline__ float4 ld4(long long i) const
+  {
+    float4 v = *reinterpret_cast<const float4 *>(p + i);
+    if constexpr (MODE == MODE_A)
+    {
+      const float4 q = *reinterpret_cast<const float4 *>(r + i);
+      v.x = fmaf(beta, v.x, q.x);
+      v.y = fmaf(beta, v.y, q.y);
+      v.z = fmaf(beta, v.z, q.z);
+      v.w = fmaf(beta, v.w, q.w);
+    }
+    return v;
+  }
+};
+
+// one axis' term in the reference's operation order: ((-u_plus) + 2*u_0) - u_minus
+// (conjugate-gradient_gpu.cu:173)
+__device__ __forceinline__ float axis_term(float up, float c, float um) { return (-up + 2.0f * c) - um; }
+
+// ---- rows engine -----------------------------------------------------------------------
+//
+// A tile is (4*blockDim.x points of axis 0) x (ty rows of axis 1) at fixed higher
+// coordinates.  GHOST: the vectors own one extra hyperplane below and above the last
+// axis (zero on a global face, the neighbour rank's data on a slab face, has_lo/has_hi).
+
+template <int MODE, bool GHOST>
+__global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
+{
+  __shared__ double sh[8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  Src<MODE> src;
+  float *__restrict__ p_new = nullptr;
+  float coef = 0;
+  if constexpr (MODE == MODE_A)
+  {
+    const IterCtl c = prologue_A(a, sh);
+    if (!c.active)
+      return;
+    src.p = (c.k & 1) ? a.p1 : a.p0;
+    p_new = (c.k & 1) ? a.p0 : a.p1;
+    src.r = a.r;
+    src.beta = c.coef;
+  }
+  else if constexpr (MODE == MODE_B)
+  {
+    const IterCtl c = prologue_B(a, sh);
+    if (!c.active)
+      return;
+    src.p = (c.k & 1) ? a.p0 : a.p1;
+    coef = c.coef;
+  }
+  else
+  {
+    src.p = a.u;
+  }
+  const float alpha = coef;
+  float acc = 0;
+  const float4 zero4 = make_float4(0, 0, 0, 0);
+  const long long n0 = g.n0;
+  const bool rowghost = GHOST && g.d == 2;
+
+  for (unsigned long long tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x)
+  {
+    unsigned long long t = tile;
+    const unsigned xc = (unsigned)(t % g.nxc);
+    t /= g.nxc;
+    const unsigned ys = (unsigned)(t % g.nstrips);
+    t /= g.nstrips;
+    long long base = 0;
+    unsigned okm = 0, okp = 0;
+    bool st_lo = false, st_hi = false;
+    for (int k = 2; k < g.d; k++)
+    {
+      const unsigned nk = g.nk[k - 2];
+      const unsigned ck = (unsigned)(t % nk);
+      t /= nk;
+      base += (long long)ck * (long long)g.sk[k - 2];
+      const bool last = GHOST && (k == g.d - 1);
+      if (ck > 0 || (last && g.has_lo))
+        okm |= 1u << (k - 2);
+      if (ck + 1 < nk || (last && g.has_hi))
+        okp |= 1u << (k - 2);
+      if (last && ck == 0 && g.has_lo)
+        st_lo = true;
+      if (last && ck + 1 == nk && g.has_hi)
+        st_hi = true;
+    }
+    const unsigned x0 = (xc * blockDim.x + tid) * 4u;
+    const bool act = x0 < g.n0;
+    const unsigned y0 = ys * g.ty;
+    const unsigned y1 = min(y0 + g.ty, g.n1);
+    long long idx = base + (long long)y0 * n0 + x0;
+    const bool el = act && lane == 0 && x0 > 0;
+    const bool er = act && lane == 63 && x0 + 4 < g.n0;
+    const bool edge = el || er;
+    const long long eoff = (lane == 0) ? -1 : 4;
+    const bool rightmost = (lane == 63) || (x0 + 4 >= g.n0);
+
+    float4 pm = zero4, pc = zero4, pn;
+    float ec = 0, en;
+    if (act && (y0 > 0 || (rowghost && g.has_lo)))
+      pm = src.ld4(idx - n0);
+    if (act)
+      pc = src.ld4(idx);
+    if (edge)
+      ec = src.ld1(idx + eoff);
+    if constexpr (MODE == MODE_A)
+    {
+      if (rowghost && g.has_lo && y0 == 0 && act)
+        *reinterpret_cast<float4 *>(p_new + idx - n0) = pm;
+    }
+
+    for (unsigned y = y0; y < y1; y++, idx += n0)
+    {
+      float4 xv, rv;
+      if constexpr (MODE == MODE_B)
+      {
+        xv = zero4;
+        rv = zero4;
+        if (act)
+        {
+          xv = *reinterpret_cast<const float4 *>(a.x + idx);
+          rv = *reinterpret_cast<const float4 *>(a.r + idx);
+        }
+      }
+      pn = zero4;
+      en = 0;
+      if (act && (y + 1 < g.n1 || (rowghost && g.has_hi)))
+        pn = src.ld4(idx + n0);
+      if (edge && y + 1 < y1)
+        en = src.ld1(idx + n0 + eoff);
+
+      float lft = __shfl_up(pc.w, 1);
+      float rgt = __shfl_down(pc.x, 1);
+      if (lane == 0)
+        lft = ec;
+      if (rightmost)
+        rgt = (lane == 63) ? ec : 0.0f;
+
+      float4 lv;
+      lv.x = 0.0f + axis_term(pc.y, pc.x, lft);
+      lv.y = 0.0f + axis_term(pc.z, pc.y, pc.x);
+      lv.z = 0.0f + axis_term(pc.w, pc.z, pc.y);
+      lv.w = 0.0f + axis_term(rgt, pc.w, pc.z);
+      if (g.d >= 2)
+      {
+        lv.x += axis_term(pn.x, pc.x, pm.x);
+        lv.y += axis_term(pn.y, pc.y, pm.y);
+        lv.z += axis_term(pn.z, pc.z, pm.z);
+        lv.w += axis_term(pn.w, pc.w, pm.w);
+      }
+      for (int k = 2; k < g.d; k++)
+      {
+        const long long s = (long long)g.sk[k - 2];
+        float4 up = zero4, um = zero4;
+        if (act && ((okp >> (k - 2)) & 1u))
+          up = src.ld4(idx + s);
+        if (act && ((okm >> (k - 2)) & 1u))
+          um = src.ld4(idx - s);
+        lv.x += axis_term(up.x, pc.x, um.x);
+        lv.y += axis_term(up.y, pc.y, um.y);
+        lv.z += axis_term(up.z, pc.z, um.z);
+        lv.w += axis_term(up.w, pc.w, um.w);
+        if constexpr (MODE == MODE_A && GHOST)
+        {
+          if (k == g.d - 1 && act)
+          {
+            if (st_lo)
+              *reinterpret_cast<float4 *>(p_new + idx - s) = um;
+            if (st_hi)
+              *reinterpret_cast<float4 *>(p_new + idx + s) = up;
+          }
+        }
+      }
+
+      if constexpr (MODE == MODE_STENCIL)
+      {
+        if (act)
+          *reinterpret_cast<float4 *>(a.out + idx) = lv;
+      }
+      else if constexpr (MODE == MODE_A)
+      {
+        if (act)
+          *reinterpret_cast<float4 *>(p_new + idx) = pc;
+        acc = fmaf(pc.x, lv.x, acc);
+        acc = fmaf(pc.y, lv.y, acc);
+        acc = fmaf(pc.z, lv.z, acc);
+        acc = fmaf(pc.w, lv.w, acc);
+      }
+      else
+      {
+        xv.x = fmaf(alpha, pc.x, xv.x);
+        xv.y = fmaf(alpha, pc.y, xv.y);
+        xv.z = fmaf(alpha, pc.z, xv.z);
+        xv.w = fmaf(alpha, pc.w, xv.w);
+        rv.x = fmaf(-alpha, lv.x, rv.x);
+        rv.y = fmaf(-alpha, lv.y, rv.y);
+        rv.z = fmaf(-alpha, lv.z, rv.z);
+        rv.w = fmaf(-alpha, lv.w, rv.w);
+        if (act)
+        {
+          *reinterpret_cast<float4 *>(a.x + idx) = xv;
+          *reinterpret_cast<float4 *>(a.r + idx) = rv;
+        }
+        acc = fmaf(rv.x, rv.x, acc);
+        acc = fmaf(rv.y, rv.y, acc);
+        acc = fmaf(rv.z, rv.z, acc);
+        acc = fmaf(rv.w, rv.w, acc);
+      }
+      pm = pc;
+      pc = pn;
+      ec = en;
+    }
+    if constexpr (MODE == MODE_A)
+    {
+      // after the loop idx addresses row y1 and pc holds it
+      if (rowghost && g.has_hi && y1 == g.n1 && act)
+        *reinterpret_cast<float4 *>(p_new + idx) = pc;
+    }
+  }
+  if constexpr (MODE != MODE_STENCIL)
+    block_write_partial(acc, a.part_out, sh);
+}
+
+// ---- scalar engine ---------------------------------------------------------------------
+
+template <int MODE, bool GHOST, int LAYOUT>
+__global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArgs a)
+{
+  __shared__ double sh[8];
+  Src<MODE> src;
+  float *__restrict__ p_new = nullptr;
+  float coef = 0;
+  if constexpr (MODE == MODE_A)
+  {
+    const IterCtl c = prologue_A(a, sh);
+    if (!c.active)
+      return;
+    src.p = (c.k & 1) ? a.p1 : a.p0;
+    p_new = (c.k & 1) ? a.p0 : a.p1;
+    src.r = a.r;
+    src.beta = c.coef;
+  }
+  else if constexpr (MODE == MODE_B)
+  {
+    const IterCtl c = prologue_B(a, sh);
+    if (!c.active)
+      return;
+    src.p = (c.k & 1) ? a.p0 : a.p1;
+    coef = c.coef;
+  }
+  else
+  {
+    src.p = a.u;
+  }
+  const float alpha = coef;
+  float acc = 0;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < g.N; i += step)
+  {
+    const float c = src.ld1((long long)i);
+    float lv = 0.0f;
+    if constexpr (LAYOUT == LAYOUT_LEX)
+    {
+      unsigned long long rem = i;
+      for (int k = 0; k < g.d; k++)
+      {
+        const unsigned nk = g.n[k];
+        const unsigned ck = (unsigned)(rem % nk);
+        rem /= nk;
+        const long long s = (long long)g.stride[k];
+        const bool last = GHOST && (k == g.d - 1);
+        const bool hp = (ck + 1 < nk) || (last && g.has_hi);
+        const bool hm = (ck > 0) || (last && g.has_lo);
+        const float up = hp ? src.ld1((long long)i + s) : 0.0f;
+        const float um = hm ? src.ld1((long long)i - s) : 0.0f;
+        lv = lv + axis_term(up, c, um);
+        if constexpr (MODE == MODE_A && GHOST)
+        {
+          if (last && g.has_lo && ck == 0)
+            p_new[(long long)i - s] = um;
+          if (last && g.has_hi && ck + 1 == nk)
+            p_new[(long long)i + s] = up;
+        }
+      }
+    }
+    else
+    {
+      // Morton: a step out of the grid lands on an index >= N (needs L = 2^m)
+      const unsigned ii = (unsigned)i;
+      for (int k = 0; k < g.d; k++)
+      {
+        const unsigned m = g.mmask[k];
+        const unsigned ip = morton_inc(ii, m);
+        const unsigned im = morton_dec(ii, m);
+        const float up = ip < g.N ? src.ld1((long long)ip) : 0.0f;
+        const float um = im < g.N ? src.ld1((long long)im) : 0.0f;
+        lv = lv + axis_term(up, c, um);
+      }
+    }
+    if constexpr (MODE == MODE_STENCIL)
+    {
+      a.out[i] = lv;
+    }
+    else if constexpr (MODE == MODE_A)
+    {
+      p_new[i] = c;
+      acc = fmaf(c, lv, acc);
+    }
+    else
+    {
+      const float xv = fmaf(alpha, c, a.x[i]);
+      const float rv = fmaf(-alpha, lv, a.r[i]);
+      a.x[i] = xv;
+      a.r[i] = rv;
+      acc = fmaf(rv, rv, acc);
+    }
+  }
+  if constexpr (MODE != MODE_STENCIL)
+    block_write_partial(acc, a.part_out, sh);
+}
+
+// ---- small kernels (defined in cg_solver.hip) ------------------------------------------
+
+// per-block partials of v.w; 16-byte loads when both pointers allow it
+__global__ void k_dot(const float *__restrict__ v, const float *__restrict__ w, unsigned long long n, int vec4,
+                      double *__restrict__ part_out);
+// out[0] = sum(part[0..n)) in the same order block_read_sum uses
+__global__ void k_sum_partials(const double *__restrict__ part, int n, double *__restrict__ out);
+// start of a solve: iteration 0, reltol = rel * |b|
+__global__ void k_init_state(CgState *st, const double *__restrict__ sumB, int nB, double rel, int lagged, int maxit);
+__global__ void k_set_maxit(CgState *st, int add);
+__global__ void k_fill_uniform(float *__restrict__ dst, unsigned long long n, unsigned int seed);
+
+// counter-based uniform [0,1): the same integer hash on host and device
+__host__ __device__ __forceinline__ float u01_hash(unsigned int seed, unsigned long long i)
+{
+  unsigned int h = (unsigned int)i * 0x9E3779B9u + seed + (unsigned int)(i >> 32) * 0x85EBCA6Bu;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+} // namespace cgamd

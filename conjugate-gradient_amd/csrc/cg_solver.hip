@@ -1,0 +1,653 @@
+// cg_solver.hip -- host side of the fused CG iteration (see cg_solver.hpp, cg_device.hpp).
+#include "cg_solver.hpp"
+
+#include <assert.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "hip_check.hpp"
+
+namespace cgamd
+{
+
+// ---- small kernels -------------------------------------------------------------------------
+
+// per-block partials of v.w; 16-byte loads when both pointers allow it
+__global__ void __launch_bounds__(256) k_dot(const float *__restrict__ v, const float *__restrict__ w,
+                                             unsigned long long n, int vec4, double *__restrict__ part_out)
+{
+  __shared__ double sh[8];
+  float acc = 0;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec4)
+  {
+    const unsigned long long n4 = n >> 2;
+    for (unsigned long long j = i; j < n4; j += step)
+    {
+      const float4 a = reinterpret_cast<const float4 *>(v)[j];
+      const float4 b = reinterpret_cast<const float4 *>(w)[j];
+      acc = fmaf(a.x, b.x, acc);
+      acc = fmaf(a.y, b.y, acc);
+      acc = fmaf(a.z, b.z, acc);
+      acc = fmaf(a.w, b.w, acc);
+    }
+    for (unsigned long long j = (n4 << 2) + i; j < n; j += step)
+      acc = fmaf(v[j], w[j], acc);
+  }
+  else
+  {
+    for (unsigned long long j = i; j < n; j += step)
+      acc = fmaf(v[j], w[j], acc);
+  }
+  block_write_partial(acc, part_out, sh);
+}
+
+// out[0] = sum(part[0..n)) in the same order block_read_sum uses
+__global__ void __launch_bounds__(64) k_sum_partials(const double *__restrict__ part, int n, double *__restrict__ out)
+{
+  __shared__ double sh[8];
+  const double s = block_read_sum(part, n, sh);
+  if (threadIdx.x == 0)
+    out[0] = s;
+}
+
+// Start of a solve: iteration 0, reltol = rel * |b| with |b| = sqrt(b.b) rounded to float the
+// way conjugate-gradient_gpu.cu:267-270,333 does it.
+__global__ void __launch_bounds__(64) k_init_state(CgState *st, const double *__restrict__ sumB, int nB, double rel,
+                                                   int lagged, int maxit)
+{
+  __shared__ double sh[8];
+  const float rr = (float)block_read_sum(sumB, nB, sh);
+  if (threadIdx.x == 0)
+  {
+    const float nrm = (float)sqrt((double)rr);
+    st->itA = 0;
+    st->doneA = 0;
+    st->itB = 0;
+    st->doneB = 0;
+    st->activeB = 0;
+    st->maxit = maxit;
+    st->lagged = lagged;
+    st->reltol = (float)(rel * (double)nrm);
+    st->alpha = 0;
+    st->beta = 0;
+    st->pAp = 0;
+    st->rr_hist[0] = rr;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_set_maxit(CgState *st, int add)
+{
+  if (threadIdx.x == 0)
+    st->maxit = st->itA + add;
+}
+
+__global__ void __launch_bounds__(256) k_fill_uniform(float *__restrict__ dst, unsigned long long n, unsigned int seed)
+{
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    dst[i] = u01_hash(seed, i);
+}
+
+
+static int env_int(const char *name, int dflt)
+{
+  const char *s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+static int max_blocks()
+{
+  int mb = env_int("CG_MAX_BLOCKS", CG_MAX_BLOCKS);
+  return std::max(1, std::min(mb, 2 * CG_MAX_BLOCKS));
+}
+
+size_t Solver::plane_of(const SolverDesc &d)
+{
+  size_t p = 1;
+  for (int k = 0; k + 1 < d.d; k++)
+    p *= d.extents[k];
+  return p;
+}
+
+size_t Solver::ghost_offset_of(const SolverDesc &d)
+{
+  // first owned element sits on a 256-byte boundary, the lo ghost plane directly below it
+  const size_t p = plane_of(d);
+  return (p + 63) / 64 * 64;
+}
+
+size_t Solver::buffer_len_of(const SolverDesc &d)
+{
+  size_t n = 1;
+  for (int k = 0; k < d.d; k++)
+    n *= d.extents[k];
+  return ghost_offset_of(d) + n + plane_of(d) + 64;
+}
+
+Solver::Solver(const SolverDesc &desc) : desc_(desc)
+{
+  CG_REQUIRE(desc.d >= 1 && desc.d <= CG_MAXD, "dimension must be in [1,32]");
+  N_ = 1;
+  for (int k = 0; k < desc.d; k++)
+  {
+    CG_REQUIRE(desc.extents[k] >= 1, "grid extents must be positive");
+    N_ *= desc.extents[k];
+  }
+  CG_REQUIRE(N_ < (1ull << 32), "grid must have fewer than 2^32 points");
+  layout_ = desc.index_mode == 2 ? LAYOUT_MORTON : LAYOUT_LEX;
+  CG_REQUIRE(desc.index_mode >= 0 && desc.index_mode <= 2, "index_mode must be 0, 1 (lexicographic) or 2 (Morton)");
+  CG_REQUIRE(!(desc.has_lo || desc.has_hi) || (layout_ == LAYOUT_LEX && desc.d >= 2),
+             "slab neighbours need the lexicographic layout and d >= 2");
+  plane_ = plane_of(desc);
+  goff_ = ghost_offset_of(desc);
+  buflen_ = buffer_len_of(desc);
+
+  if (desc.stream)
+    stream_ = desc.stream;
+  else
+  {
+    CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    own_stream_ = true;
+  }
+  auto get = [&](float *given, float *&base, bool &own) {
+    if (given)
+      base = given;
+    else
+    {
+      CHECK(hipMalloc((void **)&base, buflen_ * sizeof(float)));
+      own = true;
+    }
+  };
+  get(desc.r_buf, r_base_, own_r_);
+  get(desc.p0_buf, p0_base_, own_p0_);
+  get(desc.p1_buf, p1_base_, own_p1_);
+  r_ = r_base_ + goff_;
+  p0_ = p0_base_ + goff_;
+  p1_ = p1_base_ + goff_;
+  CG_REQUIRE(((uintptr_t)r_ % 16) == 0 && ((uintptr_t)p0_ % 16) == 0 && ((uintptr_t)p1_ % 16) == 0,
+             "solver buffers must be 16-byte aligned");
+  const size_t np = 2 * CG_MAX_BLOCKS;
+  CHECK(hipMalloc((void **)&partA_, np * sizeof(double)));
+  CHECK(hipMalloc((void **)&partB_, np * sizeof(double)));
+  CHECK(hipMalloc((void **)&st_, sizeof(CgState)));
+  CHECK(hipHostMalloc((void **)&st_host_, sizeof(CgState)));
+  CHECK(hipMemsetAsync(st_, 0, sizeof(CgState), stream_));
+  // all ghost planes start (and, on global faces, stay) zero: the Dirichlet boundary
+  CHECK(hipMemsetAsync(r_base_, 0, buflen_ * sizeof(float), stream_));
+  CHECK(hipMemsetAsync(p0_base_, 0, buflen_ * sizeof(float), stream_));
+  CHECK(hipMemsetAsync(p1_base_, 0, buflen_ * sizeof(float), stream_));
+  build_geometry();
+  sumA_ = partA_;
+  sumB_ = partB_;
+  nA_ = nB_ = grid_;
+}
+
+Solver::~Solver()
+{
+  (void)hipStreamSynchronize(stream_);
+  if (graph_)
+    (void)hipGraphExecDestroy(graph_);
+  if (own_r_)
+    (void)hipFree(r_base_);
+  if (own_p0_)
+    (void)hipFree(p0_base_);
+  if (own_p1_)
+    (void)hipFree(p1_base_);
+  (void)hipFree(partA_);
+  (void)hipFree(partB_);
+  (void)hipFree(st_);
+  (void)hipHostFree(st_host_);
+  if (own_stream_)
+    (void)hipStreamDestroy(stream_);
+}
+
+static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
+
+void Solver::build_geometry()
+{
+  const int d = desc_.d;
+  const unsigned *n = desc_.extents;
+  // scalar geometry is always filled (it also serves the Morton layout)
+  memset(&sg_, 0, sizeof(sg_));
+  sg_.d = d;
+  sg_.N = N_;
+  unsigned long long s = 1;
+  for (int k = 0; k < d; k++)
+  {
+    sg_.n[k] = n[k];
+    sg_.stride[k] = s;
+    s *= n[k];
+    sg_.mmask[k] = morton_mask(d, k);
+  }
+  sg_.has_lo = desc_.has_lo;
+  sg_.has_hi = desc_.has_hi;
+  if (layout_ == LAYOUT_MORTON)
+  {
+    int bits = 0;
+    for (int k = 0; k < d; k++)
+    {
+      CG_REQUIRE(is_pow2(n[k]) && n[k] == n[0], "the Morton layout needs equal power-of-two extents");
+    }
+    for (unsigned v = n[0]; v > 1; v >>= 1)
+      bits++;
+    CG_REQUIRE(bits * d <= 32, "the Morton index must fit 32 bits");
+  }
+
+  const bool rows_ok = layout_ == LAYOUT_LEX && (n[0] % 4 == 0) && d <= CG_ROWS_MAXD + 2;
+  engine_ = desc_.engine == ENGINE_AUTO ? (rows_ok ? ENGINE_ROWS : ENGINE_SCALAR) : desc_.engine;
+  if (engine_ == ENGINE_ROWS)
+    CG_REQUIRE(rows_ok, "the rows engine needs the lexicographic layout, n0 % 4 == 0 and d <= 10");
+
+  if (engine_ == ENGINE_ROWS)
+  {
+    memset(&rg_, 0, sizeof(rg_));
+    rg_.d = d;
+    rg_.n0 = n[0];
+    rg_.n1 = d >= 2 ? n[1] : 1;
+    const unsigned lanes = n[0] / 4;
+    block_ = (int)std::min(256u, (lanes + 63) / 64 * 64);
+    block_ = env_int("CG_ROWS_BLOCK", block_);
+    rg_.nxc = (lanes + block_ - 1) / block_;
+    unsigned long long nhi = 1;
+    for (int k = 2; k < d; k++)
+    {
+      rg_.nk[k - 2] = n[k];
+      rg_.sk[k - 2] = sg_.stride[k];
+      nhi *= n[k];
+    }
+    unsigned ty = 0;
+    const unsigned cand[4] = {64, 32, 16, 8};
+    for (unsigned c : cand)
+    {
+      if (c > rg_.n1)
+        continue;
+      const unsigned long long tiles = (unsigned long long)rg_.nxc * ((rg_.n1 + c - 1) / c) * nhi;
+      if (tiles >= (unsigned long long)max_blocks())
+      {
+        ty = c;
+        break;
+      }
+    }
+    if (!ty)
+      ty = std::min(rg_.n1, 8u);
+    ty = (unsigned)env_int("CG_ROWS_TY", (int)ty);
+    ty = std::max(1u, std::min(ty, rg_.n1));
+    rg_.ty = ty;
+    rg_.nstrips = (rg_.n1 + ty - 1) / ty;
+    rg_.ntiles = (unsigned long long)rg_.nxc * rg_.nstrips * nhi;
+    rg_.has_lo = desc_.has_lo;
+    rg_.has_hi = desc_.has_hi;
+    grid_ = (int)std::min<unsigned long long>(rg_.ntiles, (unsigned long long)max_blocks());
+  }
+  else
+  {
+    block_ = 256;
+    const unsigned long long nb = (N_ + block_ - 1) / block_;
+    grid_ = (int)std::min<unsigned long long>(nb, (unsigned long long)max_blocks());
+  }
+}
+
+VecArgs Solver::args() const
+{
+  VecArgs a{};
+  a.x = x_;
+  a.r = r_;
+  a.p0 = p0_;
+  a.p1 = p1_;
+  a.st = st_;
+  a.sumA = sumA_;
+  a.nA = nA_;
+  a.sumB = sumB_;
+  a.nB = nB_;
+  return a;
+}
+
+template <int MODE, bool GHOST>
+static void launch_rows(const RowsGeom &g, const VecArgs &a, int grid, int block, hipStream_t s)
+{
+  hipLaunchKernelGGL((k_rows<MODE, GHOST>), dim3(grid), dim3(block), 0, s, g, a);
+}
+
+template <int MODE, bool GHOST>
+static void launch_scalar(const ScalarGeom &g, const VecArgs &a, int layout, int grid, int block, hipStream_t s)
+{
+  if (layout == LAYOUT_MORTON)
+    hipLaunchKernelGGL((k_scalar<MODE, GHOST, LAYOUT_MORTON>), dim3(grid), dim3(block), 0, s, g, a);
+  else
+    hipLaunchKernelGGL((k_scalar<MODE, GHOST, LAYOUT_LEX>), dim3(grid), dim3(block), 0, s, g, a);
+}
+
+void Solver::launch_mode(int mode, bool ghost, const VecArgs &a)
+{
+  if (engine_ == ENGINE_ROWS)
+  {
+    switch (mode)
+    {
+    case MODE_A: launch_rows<MODE_A, true>(rg_, a, grid_, block_, stream_); break;
+    case MODE_B: launch_rows<MODE_B, true>(rg_, a, grid_, block_, stream_); break;
+    default:
+      if (ghost)
+        launch_rows<MODE_STENCIL, true>(rg_, a, grid_, block_, stream_);
+      else
+        launch_rows<MODE_STENCIL, false>(rg_, a, grid_, block_, stream_);
+    }
+  }
+  else
+  {
+    // Morton vectors have no ghost planes: out-of-grid is index >= N
+    const bool gh = ghost && layout_ == LAYOUT_LEX;
+    switch (mode)
+    {
+    case MODE_A:
+      if (gh)
+        launch_scalar<MODE_A, true>(sg_, a, layout_, grid_, block_, stream_);
+      else
+        launch_scalar<MODE_A, false>(sg_, a, layout_, grid_, block_, stream_);
+      break;
+    case MODE_B:
+      if (gh)
+        launch_scalar<MODE_B, true>(sg_, a, layout_, grid_, block_, stream_);
+      else
+        launch_scalar<MODE_B, false>(sg_, a, layout_, grid_, block_, stream_);
+      break;
+    default:
+      if (gh)
+        launch_scalar<MODE_STENCIL, true>(sg_, a, layout_, grid_, block_, stream_);
+      else
+        launch_scalar<MODE_STENCIL, false>(sg_, a, layout_, grid_, block_, stream_);
+    }
+  }
+  CHECK(hipGetLastError());
+}
+
+void Solver::launch_A()
+{
+  VecArgs a = args();
+  a.part_out = partA_;
+  launch_mode(MODE_A, true, a);
+}
+
+void Solver::launch_B()
+{
+  VecArgs a = args();
+  a.part_out = partB_;
+  launch_mode(MODE_B, true, a);
+}
+
+void Solver::launch_stencil(const float *u, float *out, bool ghost)
+{
+  VecArgs a{};
+  a.u = u;
+  a.out = out;
+  launch_mode(MODE_STENCIL, ghost, a);
+}
+
+static void launch_dot(const float *v, const float *w, unsigned long long n, double *part, int grid, hipStream_t s)
+{
+  const int vec4 = (((uintptr_t)v | (uintptr_t)w) % 16 == 0) ? 1 : 0;
+  hipLaunchKernelGGL(k_dot, dim3(grid), dim3(256), 0, s, v, w, n, vec4, part);
+  CHECK(hipGetLastError());
+}
+
+void Solver::begin_local(const float *b_dev, float *x_dev)
+{
+  x_ = x_dev;
+  if (graph_ && graph_x_ != x_dev)
+  {
+    CHECK(hipGraphExecDestroy(graph_));
+    graph_ = nullptr;
+  }
+  CHECK(hipMemcpyAsync(r_, b_dev, N_ * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+  // p_old of iteration 0 must be finite everywhere it is read: beta = 0 then gives p = r exactly
+  CHECK(hipMemsetAsync(p0_base_, 0, buflen_ * sizeof(float), stream_));
+  launch_dot(r_, r_, N_, partB_, grid_, stream_);
+}
+
+void Solver::reduce_partials(int which, double *out_dev)
+{
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, stream_, which ? partB_ : partA_, grid_, out_dev);
+  CHECK(hipGetLastError());
+}
+
+void Solver::bind_sums(const double *sumA, int nA, const double *sumB, int nB)
+{
+  sumA_ = sumA ? sumA : partA_;
+  nA_ = sumA ? nA : grid_;
+  sumB_ = sumB ? sumB : partB_;
+  nB_ = sumB ? nB : grid_;
+  if (graph_)
+  {
+    CHECK(hipGraphExecDestroy(graph_));
+    graph_ = nullptr;
+  }
+}
+
+void Solver::init_state(double rel, int lagged, int maxit)
+{
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, stream_, st_, sumB_, nB_, rel, lagged, maxit);
+  CHECK(hipGetLastError());
+}
+
+void Solver::add_iterations(int n)
+{
+  hipLaunchKernelGGL(k_set_maxit, dim3(1), dim3(64), 0, stream_, st_, n);
+  CHECK(hipGetLastError());
+}
+
+void Solver::begin(const float *b_dev, float *x_dev, double rel, int lagged)
+{
+  begin_local(b_dev, x_dev);
+  init_state(rel, lagged, 0);
+}
+
+void Solver::iterate(int n, bool use_graph)
+{
+  if (n <= 0)
+    return;
+  add_iterations(n);
+  const int chunk = std::max(1, env_int("CG_GRAPH_ITERS", 20));
+  if (!use_graph)
+  {
+    for (int i = 0; i < n; i++)
+    {
+      launch_A();
+      launch_B();
+    }
+    return;
+  }
+  if (!graph_ || graph_iters_ != chunk)
+  {
+    if (graph_)
+      CHECK(hipGraphExecDestroy(graph_));
+    hipGraph_t g;
+    CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < chunk; i++)
+    {
+      launch_A();
+      launch_B();
+    }
+    CHECK(hipStreamEndCapture(stream_, &g));
+    CHECK(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
+    CHECK(hipGraphDestroy(g));
+    graph_iters_ = chunk;
+    graph_x_ = x_;
+  }
+  // iterations beyond maxit are device-side no-ops, so whole chunks are always safe
+  for (int done = 0; done < n; done += chunk)
+    CHECK(hipGraphLaunch(graph_, stream_));
+}
+
+void Solver::run(int maxit, bool use_graph, int poll)
+{
+  long long left = maxit < 0 ? (1ll << 40) : maxit;
+  CgState s;
+  while (left > 0)
+  {
+    const int n = (int)std::min<long long>(left, poll);
+    iterate(n, use_graph);
+    left -= n;
+    read_state(&s);
+    if (s.doneA)
+      break;
+  }
+}
+
+void Solver::read_state(CgState *host_copy)
+{
+  CHECK(hipMemcpyAsync(st_host_, st_, sizeof(CgState), hipMemcpyDeviceToHost, stream_));
+  CHECK(hipStreamSynchronize(stream_));
+  *host_copy = *st_host_;
+}
+
+int Solver::finish(float *residue, float *hist, int hist_len)
+{
+  CgState s;
+  read_state(&s);
+  const int n = s.itA;
+  // the reference returns the lagged value sqrt(rr at the start of the last iteration),
+  // conjugate-gradient_gpu.cu:366,375; with no iteration it returns |r0|
+  const int last = n > 0 ? n - 1 : 0;
+  if (residue)
+    *residue = (float)sqrt((double)s.rr_hist[last % CG_HIST]);
+  if (hist)
+  {
+    // hist[i] = value printed after iteration i+1 (:369); only the last CG_HIST are kept
+    for (int i = 0; i < n && i < hist_len; i++)
+      hist[i] = (n - i < CG_HIST) ? (float)sqrt((double)s.rr_hist[i % CG_HIST]) : NAN;
+  }
+  return n;
+}
+
+void Solver::time_kernels(int n, float *ms_A, float *ms_B)
+{
+  std::vector<hipEvent_t> ev(3 * (size_t)n);
+  for (auto &e : ev)
+    CHECK(hipEventCreate(&e));
+  add_iterations(n);
+  for (int i = 0; i < n; i++)
+  {
+    CHECK(hipEventRecord(ev[3 * i], stream_));
+    launch_A();
+    CHECK(hipEventRecord(ev[3 * i + 1], stream_));
+    launch_B();
+    CHECK(hipEventRecord(ev[3 * i + 2], stream_));
+  }
+  CHECK(hipStreamSynchronize(stream_));
+  double ta = 0, tb = 0;
+  for (int i = 0; i < n; i++)
+  {
+    float m;
+    CHECK(hipEventElapsedTime(&m, ev[3 * i], ev[3 * i + 1]));
+    ta += m;
+    CHECK(hipEventElapsedTime(&m, ev[3 * i + 1], ev[3 * i + 2]));
+    tb += m;
+  }
+  for (auto &e : ev)
+    CHECK(hipEventDestroy(e));
+  if (ms_A)
+    *ms_A = (float)(ta / n);
+  if (ms_B)
+    *ms_B = (float)(tb / n);
+}
+
+// ---- free functions ---------------------------------------------------------------------
+
+void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode, hipStream_t stream)
+{
+  CG_REQUIRE(d >= 1 && d <= CG_MAXD, "dimension must be in [1,32]");
+  const int layout = index_mode == 2 ? LAYOUT_MORTON : LAYOUT_LEX;
+  ScalarGeom sg{};
+  sg.d = d;
+  unsigned long long s = 1;
+  for (int k = 0; k < d; k++)
+  {
+    sg.n[k] = L;
+    sg.stride[k] = s;
+    s *= L;
+    sg.mmask[k] = morton_mask(d, k);
+  }
+  sg.N = s;
+  VecArgs a{};
+  a.u = u;
+  a.out = ddf;
+  const bool aligned = (((uintptr_t)u | (uintptr_t)ddf) % 16) == 0;
+  if (layout == LAYOUT_LEX && L % 4 == 0 && d <= CG_ROWS_MAXD + 2 && aligned)
+  {
+    RowsGeom g{};
+    g.d = d;
+    g.n0 = L;
+    g.n1 = d >= 2 ? L : 1;
+    const unsigned lanes = L / 4;
+    const int block = (int)std::min(256u, (lanes + 63) / 64 * 64);
+    g.nxc = (lanes + block - 1) / block;
+    unsigned long long nhi = 1;
+    for (int k = 2; k < d; k++)
+    {
+      g.nk[k - 2] = L;
+      g.sk[k - 2] = sg.stride[k];
+      nhi *= L;
+    }
+    unsigned ty = std::min(g.n1, 8u);
+    const unsigned cand[4] = {64, 32, 16, 8};
+    for (unsigned c : cand)
+      if (c <= g.n1 && (unsigned long long)g.nxc * ((g.n1 + c - 1) / c) * nhi >= (unsigned long long)max_blocks())
+      {
+        ty = c;
+        break;
+      }
+    g.ty = ty;
+    g.nstrips = (g.n1 + ty - 1) / ty;
+    g.ntiles = (unsigned long long)g.nxc * g.nstrips * nhi;
+    const int grid = (int)std::min<unsigned long long>(g.ntiles, (unsigned long long)max_blocks());
+    launch_rows<MODE_STENCIL, false>(g, a, grid, block, stream);
+  }
+  else
+  {
+    if (layout == LAYOUT_MORTON)
+    {
+      int bits = 0;
+      for (unsigned v = L; v > 1; v >>= 1)
+        bits++;
+      CG_REQUIRE(is_pow2(L) && bits * d <= 32, "the Morton layout needs L = 2^m with m*d <= 32");
+    }
+    const unsigned long long nb = (sg.N + 255) / 256;
+    const int grid = (int)std::min<unsigned long long>(nb, (unsigned long long)max_blocks());
+    launch_scalar<MODE_STENCIL, false>(sg, a, layout, grid, 256, stream);
+  }
+  CHECK(hipGetLastError());
+}
+
+double dot_device(const float *v, const float *w, unsigned long long n, hipStream_t stream)
+{
+  static double *part = nullptr;
+  static double *host = nullptr;
+  if (!part)
+  {
+    CHECK(hipMalloc((void **)&part, (2 * CG_MAX_BLOCKS + 1) * sizeof(double)));
+    CHECK(hipHostMalloc((void **)&host, sizeof(double)));
+  }
+  const unsigned long long nb = (n / 4 + 255) / 256 + 1;
+  const int grid = (int)std::min<unsigned long long>(nb, (unsigned long long)max_blocks());
+  launch_dot(v, w, n, part, grid, stream);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, stream, part, grid, part + 2 * CG_MAX_BLOCKS);
+  CHECK(hipGetLastError());
+  CHECK(hipMemcpyAsync(host, part + 2 * CG_MAX_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, stream));
+  CHECK(hipStreamSynchronize(stream));
+  return *host;
+}
+
+void fill_uniform(float *dst, unsigned long long n, unsigned int seed, hipStream_t stream)
+{
+  const unsigned long long nb = (n + 255) / 256;
+  const int grid = (int)std::min<unsigned long long>(nb, 4096ull);
+  hipLaunchKernelGGL(k_fill_uniform, dim3(grid), dim3(256), 0, stream, dst, n, seed);
+  CHECK(hipGetLastError());
+}
+
+} // namespace cgamd

@@ -1,0 +1,116 @@
+// cg_solver.hpp -- host control of the fused CG iteration (single precision, one GPU or
+// one slab of a multi-GPU grid).  Mirrors the loop of conjugate-gradient_gpu.cu:327-376
+// with alpha/beta, the iteration counter and the stop test on the device; the host only
+// enqueues launches (optionally replayed from a hipGraph) and reads the state back once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "cg_device.hpp"
+
+namespace cgamd
+{
+
+enum Engine
+{
+  ENGINE_AUTO = 0,
+  ENGINE_ROWS = 1,
+  ENGINE_SCALAR = 2
+};
+
+struct SolverDesc
+{
+  int d = 0;
+  unsigned extents[CG_MAXD] = {0};
+  int index_mode = 0;            // 0,1: lexicographic (identical, as in the reference); 2: Morton
+  int has_lo = 0, has_hi = 0;    // this slab has a neighbour below / above along the last axis
+  hipStream_t stream = nullptr;  // nullptr: the solver creates its own
+  float *r_buf = nullptr;        // optional caller-owned storage, buffer_len() floats each
+  float *p0_buf = nullptr;
+  float *p1_buf = nullptr;
+  int engine = ENGINE_AUTO;
+};
+
+class Solver
+{
+public:
+  explicit Solver(const SolverDesc &desc);
+  ~Solver();
+  Solver(const Solver &) = delete;
+  Solver &operator=(const Solver &) = delete;
+
+  // geometry of the ghosted vectors: [pad | lo ghost plane | N owned | hi ghost plane]
+  static size_t plane_of(const SolverDesc &d);
+  static size_t ghost_offset_of(const SolverDesc &d); // floats before the first owned element
+  static size_t buffer_len_of(const SolverDesc &d);
+  size_t N() const { return N_; }
+  size_t plane() const { return plane_; }
+  size_t ghost_offset() const { return goff_; }
+  hipStream_t stream() const { return stream_; }
+  float *r() const { return r_; }   // first owned element
+  float *p(int which) const { return which ? p1_ : p0_; }
+  double *partials(int which) const { return which ? partB_ : partA_; }
+  int engine() const { return engine_; }
+  int blocks() const { return grid_; }
+
+  // ---- whole-solve interface (all asynchronous on stream() until finish) -------------
+  // r = b, p = 0, r.r; x is the caller's device vector of N floats and is accumulated into
+  void begin(const float *b_dev, float *x_dev, double rel, int lagged);
+  // enqueue n more iterations (they become no-ops once the stop test has fired)
+  void iterate(int n, bool use_graph);
+  // wait, return the number of executed iterations; residue = what the reference returns
+  int finish(float *residue, float *hist, int hist_len);
+  // enqueue up to maxit iterations (maxit < 0: unbounded), polling the device stop flag
+  // every `poll` iterations so that a converged solve stops launching; synchronous
+  void run(int maxit, bool use_graph, int poll = 40);
+
+  // ---- step interface for the slab driver (scalars all-reduced between the steps) -----
+  void begin_local(const float *b_dev, float *x_dev);         // r = b, p0 = 0, partials(1) = local r.r
+  void reduce_partials(int which, double *out_dev);           // out[0] = sum of partials(which)
+  void bind_sums(const double *sumA, int nA, const double *sumB, int nB);
+  void init_state(double rel, int lagged, int maxit);         // from the bound r.r sum
+  void add_iterations(int n);                                 // maxit = it + n
+  void launch_A();
+  void launch_B();
+  void launch_stencil(const float *u, float *out, bool ghost); // out = A u with this geometry
+  void read_state(CgState *host_copy);                        // synchronises
+
+  // per-kernel device time over n iterations, HIP events on stream(); plain launches
+  void time_kernels(int n, float *ms_A, float *ms_B);
+
+private:
+  void build_geometry();
+  void launch_mode(int mode, bool ghost, const VecArgs &a);
+  VecArgs args() const;
+
+  SolverDesc desc_;
+  size_t N_ = 0, plane_ = 0, goff_ = 0, buflen_ = 0;
+  hipStream_t stream_ = nullptr;
+  bool own_stream_ = false, own_r_ = false, own_p0_ = false, own_p1_ = false;
+  float *r_base_ = nullptr, *p0_base_ = nullptr, *p1_base_ = nullptr;
+  float *r_ = nullptr, *p0_ = nullptr, *p1_ = nullptr, *x_ = nullptr;
+  double *partA_ = nullptr, *partB_ = nullptr;
+  const double *sumA_ = nullptr, *sumB_ = nullptr;
+  int nA_ = 0, nB_ = 0;
+  CgState *st_ = nullptr;
+  CgState *st_host_ = nullptr;
+  int engine_ = ENGINE_SCALAR;
+  int layout_ = LAYOUT_LEX;
+  RowsGeom rg_{};
+  ScalarGeom sg_{};
+  int grid_ = 1, block_ = 256;
+  hipGraphExec_t graph_ = nullptr;
+  int graph_iters_ = 0;
+  float *graph_x_ = nullptr;
+};
+
+// y = A u for caller-owned arrays without ghost planes (u may have N or N+1 entries; the
+// boundary slot is never read).  Synchronous on the given stream only if sync is set.
+void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode, hipStream_t stream);
+
+// deterministic two-stage dot product; returns the double sum
+double dot_device(const float *v, const float *w, unsigned long long n, hipStream_t stream);
+
+void fill_uniform(float *dst, unsigned long long n, unsigned int seed, hipStream_t stream);
+
+} // namespace cgamd

@@ -1,0 +1,247 @@
+// mixed_precision.hip -- outer double-precision CG preconditioned by the float GPU CG
+// (the outer loop of conjugate-gradient_cpu.cu:334-392; readme.md:81 and tasks.md:7-8 name
+// the float GPU solver as the inner solve).  Vectors stay on the device; only the scalars
+// alpha, beta and the norms travel to the host, which runs the control flow in double
+// exactly as the reference does.
+#include <math.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/conjugate_gradient_gpu.h"
+#include "cg_solver.hpp"
+#include "hip_check.hpp"
+
+namespace cgamd
+{
+
+// w = A u in double, lexicographic, zero Dirichlet boundary (conjugate-gradient_cpu.cu:97-113)
+__global__ void __launch_bounds__(256) k_laplace_f64(double *__restrict__ w, const double *__restrict__ u, int d,
+                                                     unsigned L, unsigned long long N)
+{
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += step)
+  {
+    const double c = u[i];
+    double lv = 0;
+    unsigned long long rem = i, s = 1;
+    for (int k = 0; k < d; k++)
+    {
+      const unsigned ck = (unsigned)(rem % L);
+      rem /= L;
+      const double up = (ck + 1 < L) ? u[i + s] : 0.0;
+      const double um = (ck > 0) ? u[i - s] : 0.0;
+      lv = lv + ((-up + 2 * c) - um);
+      s *= L;
+    }
+    w[i] = lv;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dot_f64(const double *__restrict__ v, const double *__restrict__ w,
+                                                 unsigned long long n, double *__restrict__ part)
+{
+  __shared__ double sh[8];
+  double acc = 0;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    acc = fma(v[i], w[i], acc);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0)
+    sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// x += a p ; r -= a w
+__global__ void __launch_bounds__(256) k_update_f64(double *__restrict__ x, double *__restrict__ r,
+                                                    const double *__restrict__ p, const double *__restrict__ w, double a,
+                                                    unsigned long long n)
+{
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+  {
+    x[i] = x[i] + a * p[i];
+    r[i] = r[i] - a * w[i];
+  }
+}
+
+// p = z + beta p
+__global__ void __launch_bounds__(256) k_xpay_f64(double *__restrict__ p, const double *__restrict__ z, double beta,
+                                                  unsigned long long n)
+{
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    p[i] = z[i] + beta * p[i];
+}
+
+// r = b - w
+__global__ void __launch_bounds__(256) k_sub_f64(double *__restrict__ r, const double *__restrict__ b,
+                                                 const double *__restrict__ w, unsigned long long n)
+{
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    r[i] = b[i] - w[i];
+}
+
+__global__ void __launch_bounds__(256) k_narrow(float *__restrict__ dst, const double *__restrict__ src,
+                                                unsigned long long n)
+{
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    dst[i] = (float)src[i];
+}
+
+__global__ void __launch_bounds__(256) k_widen(double *__restrict__ dst, const float *__restrict__ src,
+                                               unsigned long long n)
+{
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    dst[i] = (double)src[i];
+}
+
+struct Mixed
+{
+  hipStream_t s;
+  unsigned long long N;
+  int grid;
+  double *part, *out;
+  double *host;
+
+  double dot(const double *v, const double *w)
+  {
+    hipLaunchKernelGGL(k_dot_f64, dim3(grid), dim3(256), 0, s, v, w, N, part);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, s, part, grid, out);
+    CHECK(hipGetLastError());
+    CHECK(hipMemcpyAsync(host, out, sizeof(double), hipMemcpyDeviceToHost, s));
+    CHECK(hipStreamSynchronize(s));
+    return *host;
+  }
+};
+
+} // namespace cgamd
+
+using namespace cgamd;
+
+static bool is_device_ptr(const void *p)
+{
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeDevice;
+}
+
+extern "C" int preconditioned_cg_gpu(const double *b, double *x, int L, int d, int *inner_iters, int inner_len,
+                                     int verbose)
+{
+  CG_REQUIRE(L >= 1 && d >= 1 && d <= CG_MAXD, "need L >= 1 and 1 <= d <= 32");
+  unsigned long long N = 1;
+  for (int k = 0; k < d; k++)
+    N *= (unsigned)L;
+  CG_REQUIRE(N < (1ull << 31), "grid must fit an int, as in the reference");
+
+  SolverDesc desc;
+  desc.d = d;
+  for (int k = 0; k < d; k++)
+    desc.extents[k] = (unsigned)L;
+  Solver inner(desc);
+  hipStream_t s = inner.stream();
+
+  Mixed m;
+  m.s = s;
+  m.N = N;
+  m.grid = (int)std::min<unsigned long long>((N + 255) / 256, 2048ull);
+  CHECK(hipMalloc((void **)&m.part, (m.grid + 1) * sizeof(double)));
+  m.out = m.part + m.grid;
+  CHECK(hipHostMalloc((void **)&m.host, sizeof(double)));
+
+  const size_t bytes = N * sizeof(double);
+  double *xd, *bd, *r, *p, *w;
+  float *rf, *zf;
+  const bool x_dev = is_device_ptr(x), b_dev = is_device_ptr(b);
+  if (x_dev)
+    xd = x;
+  else
+  {
+    CHECK(hipMalloc((void **)&xd, bytes));
+    CHECK(hipMemcpy(xd, x, bytes, hipMemcpyDefault));
+  }
+  if (b_dev)
+    bd = const_cast<double *>(b);
+  else
+  {
+    CHECK(hipMalloc((void **)&bd, bytes));
+    CHECK(hipMemcpy(bd, b, bytes, hipMemcpyDefault));
+  }
+  CHECK(hipMalloc((void **)&r, bytes));
+  CHECK(hipMalloc((void **)&p, bytes));
+  CHECK(hipMalloc((void **)&w, bytes));
+  CHECK(hipMalloc((void **)&rf, N * sizeof(float)));
+  CHECK(hipMalloc((void **)&zf, N * sizeof(float)));
+  const dim3 G(m.grid), B(256);
+
+  int ncalls = 0;
+  // z = M^-1 r: float CG from 0 until |r_inner| <= 1e-3 |r| on the fresh residual, no cap
+  // (conjugate-gradient_cpu.cu:274-324), result widened into `dst`
+  auto precondition = [&](const double *rhs, double *dst) {
+    hipLaunchKernelGGL(k_narrow, G, B, 0, s, rf, rhs, N);
+    CHECK(hipMemsetAsync(zf, 0, N * sizeof(float), s));
+    inner.begin(rf, zf, 1e-3, 0);
+    inner.run(-1, true);
+    const int it = inner.finish(nullptr, nullptr, 0);
+    if (verbose)
+      printf("number of steps inner %d\n", it);
+    if (inner_iters && ncalls < inner_len)
+      inner_iters[ncalls] = it;
+    ncalls++;
+    hipLaunchKernelGGL(k_widen, G, B, 0, s, dst, zf, N);
+    CHECK(hipGetLastError());
+  };
+
+  hipLaunchKernelGGL(k_laplace_f64, G, B, 0, s, w, xd, d, (unsigned)L, N);
+  hipLaunchKernelGGL(k_sub_f64, G, B, 0, s, r, bd, w, N);
+  const double tol = 1e-8 * sqrt(m.dot(bd, bd));
+  precondition(r, p);
+  CHECK(hipMemcpyAsync(w, p, bytes, hipMemcpyDeviceToDevice, s));
+  double rMinvr = m.dot(r, w);
+  int it = 0;
+  const int maxitter = 1000;
+  while (it < maxitter)
+  {
+    it++;
+    hipLaunchKernelGGL(k_laplace_f64, G, B, 0, s, w, p, d, (unsigned)L, N);
+    const double alpha = rMinvr / m.dot(p, w);
+    hipLaunchKernelGGL(k_update_f64, G, B, 0, s, xd, r, p, w, alpha, N);
+    if (sqrt(m.dot(r, r)) < tol)
+      break;
+    precondition(r, w);
+    const double rMinvr_new = m.dot(r, w);
+    const double beta = rMinvr_new / rMinvr;
+    hipLaunchKernelGGL(k_xpay_f64, G, B, 0, s, p, w, beta, N);
+    rMinvr = rMinvr_new;
+  }
+  CHECK(hipGetLastError());
+  CHECK(hipStreamSynchronize(s));
+  if (verbose)
+    printf("number of steps (outer) %i\n", it);
+  if (!x_dev)
+  {
+    CHECK(hipMemcpy(x, xd, bytes, hipMemcpyDefault));
+    CHECK(hipFree(xd));
+  }
+  if (!b_dev)
+    CHECK(hipFree(bd));
+  CHECK(hipFree(r));
+  CHECK(hipFree(p));
+  CHECK(hipFree(w));
+  CHECK(hipFree(rf));
+  CHECK(hipFree(zf));
+  CHECK(hipFree(m.part));
+  CHECK(hipHostFree(m.host));
+  return it;
+}

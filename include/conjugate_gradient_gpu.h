@@ -1,0 +1,149 @@
+/* conjugate_gradient_gpu.h -- C-ABI of libconjugate_gradient_gpu.so (MI355X / gfx950).
+ *
+ * Part 1 is the drop-in boundary: exactly the unmangled symbols the reference's shared
+ * library exports and its Julia driver binds with dlsym + @ccall
+ * (/root/reference/src/main.jl:13-58), with the same argument meaning, return values and
+ * error behaviour (runtime errors print "Error: file:line, code: N, reason: ..." to
+ * stderr and exit(1), common.h:7-17; non-convergence is not an error).
+ * Part 2 are additions that the reference API cannot express (layout choice, fixed
+ * iteration counts, device-resident benchmarking, slab decomposition, mixed precision).
+ *
+ * Pointers are plain float / double pointers.  Device, managed and host pointers are all
+ * accepted by part 1 (non-device memory is staged through HBM); part 2 documents what
+ * each argument must be.  All functions are synchronous on return unless stated.
+ * Single host thread per solver object; one GPU (the current HIP device).
+ */
+#ifndef CONJUGATE_GRADIENT_GPU_H
+#define CONJUGATE_GRADIENT_GPU_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+  /* ===================== Part 1: the reference's exports ============================ */
+
+  /* conjugate-gradient_gpu.cuh:47, conjugate-gradient_gpu.cu:327-376; main.jl:41-44.
+   * Float CG for A x = b on the L^d grid, A = discrete Laplacian with zero Dirichlet
+   * boundary.  r = b (x is assumed 0 and is accumulated into), reltol = 1e-6*|b|, at most
+   * 200 iterations, the loop tests the residual of the previous iteration and that lagged
+   * value is returned.  Prints "i,residue" per iteration to stdout as the reference does
+   * (after the solve; set CG_GPU_QUIET=1 to suppress). */
+  float conjugate_gradient_gpu(float *b, float *x, int L, int d);
+
+  /* conjugate-gradient_gpu.cuh:26, conjugate-gradient_gpu.cu:239-255; main.jl:28-32.
+   * sum_i v[i]*w[i] over N floats.  Deterministic (two-stage, no atomics). */
+  float inner_product_gpu(float *v, float *w, unsigned int N);
+
+  /* conjugate-gradient_gpu.cuh:16-18, conjugate-gradient_gpu.cu:128-148; main.jl:34-37.
+   * Host-callable.  Neighbour of `ind` at amount in {-1,0,1} along `direction`; N if the
+   * step leaves the grid.  index_mode 0 and 1: lexicographic (identical, as in the
+   * reference, where the argument is ignored); 2: Morton (interleave.cuh:43-67). */
+  unsigned int neighbour_index_gpu(unsigned int ind, int direction, int amount, unsigned int L, unsigned int d,
+                                   unsigned int N, int index_mode);
+
+  /* julia.cu:16-30; main.jl:47-51.  Microseconds of one stencil launch of
+   * nblocks x threads_per_block threads (one grid point per thread) plus synchronisation,
+   * on device-resident random data. */
+  float strong_scaling(int nblocks, int threads_per_block, int N, int L, int d);
+
+  /* julia.cu:32-42; main.jl:54-58.  Microseconds of one CPU (double) stencil. */
+  float time_cpu_laplace(int N, int L, int d);
+
+  /* julia.cu:44-53; main.jl:16-19.  A[i] += B[i] for i < blocks*threads (no bounds check,
+   * as in the reference).  Asynchronous. */
+  void add_jl(float *A, float *B, int blocks, int threads);
+
+  /* julia.cu:55-60; main.jl:22-25.  ddf = A u for the first min(N, blocks*threads) points;
+   * dx is ignored (the discrete operator carries no dx, conjugate-gradient_gpu.cu:175).
+   * u may have N or N+1 entries: out-of-grid neighbours are literal zeros. */
+  void laplace_gpu_jl(float *ddf, float *u, float dx, int d, int L, int N, unsigned int index_mode,
+                      unsigned int blocks, unsigned int threads);
+
+  /* ===================== Part 2: additions =========================================== */
+
+  /* cuda_allocate_field (conjugate-gradient_gpu.cuh:10, .cu:34-42) with C linkage: N+1
+   * zeroed floats that host and device can both dereference; slot N is the boundary. */
+  float *cg_allocate_field(int N);
+  void cg_free_field(float *field);
+
+  /* conjugate_gradient_gpu with its constants exposed.  index_mode as above (2 = vectors in
+   * Morton order); maxit < 0: no cap; rel: relative tolerance; lagged 1: reference GPU stop
+   * rule, 0: stop on the fresh residual (the CPU preconditioner's rule,
+   * conjugate-gradient_cpu.cu:299,317); verbose: replay the reference's per-iteration
+   * printf.  iters_out / hist (hist_len floats, the printed residues) may be NULL. */
+  float conjugate_gradient_gpu_ex(const float *b, float *x, int L, int d, int index_mode, int maxit, double rel,
+                                  int lagged, int verbose, int *iters_out, float *hist, int hist_len);
+
+  /* Mixed precision (conjugate-gradient_cpu.cu:334-392 with the float GPU solver as the
+   * inner solve, the scheme the reference's readme.md:81 describes): outer CG in double
+   * to 1e-8*|b| (cap 1000), M^-1 r by conjugate_gradient_gpu_ex(rel 1e-3, fresh-residual
+   * rule).  b, x: N doubles, host or device; x is the initial guess and the result.
+   * Returns the number of outer iterations; inner_iters (inner_len ints) receives the
+   * inner step counts. */
+  int preconditioned_cg_gpu(const double *b, double *x, int L, int d, int *inner_iters, int inner_len,
+                            int verbose);
+
+  /* y = A u on device pointers, asynchronous on `stream` (a hipStream_t, may be NULL). */
+  void cg_laplace_device(float *ddf, const float *u, int d, int L, int index_mode, void *stream);
+
+  /* dst[i] = u01(seed, i): counter-based uniform [0,1) generator, identical on host
+   * (cg_u01_host) and device.  dst: device pointer. */
+  void cg_fill_uniform(float *dst, unsigned long long n, unsigned int seed);
+  float cg_u01_host(unsigned int seed, unsigned long long i);
+
+  /* --- solver object: the fused two-kernel iteration on device-resident vectors -------- */
+
+  typedef struct cg_solver cg_solver;
+
+  typedef struct cg_solver_desc
+  {
+    int d;                 /* dimensions, 1..32 */
+    unsigned extents[32];  /* points per axis, axis 0 contiguous; last axis = slab axis */
+    int index_mode;        /* 0,1 lexicographic; 2 Morton */
+    int has_lo, has_hi;    /* a neighbouring slab exists below / above the last axis */
+    void *stream;          /* hipStream_t to enqueue on; NULL = private stream */
+    float *r_buf;          /* optional caller-owned buffers of cg_solver_buffer_len() */
+    float *p0_buf;         /*   floats (16-byte aligned device memory); NULL = allocate. */
+    float *p1_buf;         /*   Layout: [pad | lo ghost plane | N owned | hi ghost plane] */
+    int engine;            /* 0 auto, 1 rows (vectorised), 2 scalar */
+  } cg_solver_desc;
+
+  size_t cg_solver_buffer_len(const cg_solver_desc *desc);   /* floats per buffer */
+  size_t cg_solver_ghost_offset(const cg_solver_desc *desc); /* floats before the first owned element */
+  size_t cg_solver_plane(const cg_solver_desc *desc);        /* floats in one ghost plane */
+
+  cg_solver *cg_solver_create(const cg_solver_desc *desc);
+  void cg_solver_destroy(cg_solver *s);
+  int cg_solver_engine(const cg_solver *s);
+  int cg_solver_blocks(const cg_solver *s);
+
+  /* whole solve, asynchronous until cg_solver_finish.  b, x: device pointers, N floats. */
+  void cg_solver_begin(cg_solver *s, const float *b, float *x, double rel, int lagged);
+  void cg_solver_iterate(cg_solver *s, int n_iters, int use_graph);
+  int cg_solver_finish(cg_solver *s, float *residue, float *hist, int hist_len);
+  void cg_solver_sync(cg_solver *s);
+
+  /* average device milliseconds of kernel A and kernel B over n further iterations
+   * (HIP events on the solver's stream, plain launches) */
+  void cg_solver_time_kernels(cg_solver *s, int n_iters, float *ms_A, float *ms_B);
+
+  /* step interface for slab decomposition: the caller all-reduces the two dot products
+   * between the steps (device doubles) and exchanges r's boundary planes.  All calls are
+   * asynchronous on the solver's stream. */
+  void cg_solver_begin_local(cg_solver *s, const float *b, float *x);   /* r = b, p = 0, local r.r partials */
+  void cg_solver_reduce(cg_solver *s, int which, double *out);          /* out[0] = local p.Ap (0) or r.r (1) */
+  void cg_solver_bind_sums(cg_solver *s, const double *pAp, const double *rr); /* all-reduced values */
+  void cg_solver_init_state(cg_solver *s, double rel, int lagged, int maxit);
+  void cg_solver_add_iterations(cg_solver *s, int n);
+  void cg_solver_kernel_A(cg_solver *s);
+  void cg_solver_kernel_B(cg_solver *s);
+  float *cg_solver_r(cg_solver *s);              /* first owned element of r */
+  float *cg_solver_p(cg_solver *s, int which);   /* first owned element of p0 / p1 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,33 @@
+// conjugate_gradient_gpu.hpp -- C++ (hipcc) host API of libconjugate_gradient_gpu.so: the
+// declarations a HIP translation unit needs to be a caller in the way the reference's
+// main.cu / tests.cu are callers of conjugate-gradient_gpu.cuh:10-50.  The kernels keep
+// the reference's names and parameters and may be launched with any 1-D shape.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conjugate_gradient_gpu.h"
+
+// conjugate-gradient_gpu.cuh:10 -- N+1 zeroed floats, host- and device-dereferenceable
+float *cuda_allocate_field(int N);
+
+// conjugate-gradient_gpu.cuh:20-21 -- one grid point per thread; index_mode 0/1
+// lexicographic, 2 Morton; out-of-grid neighbours are zero (slot N is never read)
+__global__ void laplace_gpu(float *ddf, float *u, unsigned int d, unsigned int L, unsigned int N,
+                            unsigned int index_mode);
+
+// conjugate-gradient_gpu.cuh:23-24 -- *g_odata += sum v[i]*w[i]; g_odata must be zeroed by
+// the caller; dynamic LDS of nthreads floats is accepted and unused
+__global__ void reduceMulAddComplete(float *v, float *w, float *g_odata, unsigned int n, const unsigned int nthreads);
+
+// conjugate-gradient_gpu.cu:293-308
+__global__ void muladd(float *A, float b, float *B, int N);
+__global__ void muladd3(float *A, float *C, float b, float *B, int N);
+
+// conjugate-gradient_gpu.cuh:49
+__global__ void fillArray(float *arr, float value, int size);
+
+// conjugate-gradient_gpu.cuh:28
+float norm(float *v, int N);
+
+// conjugate-gradient_gpu.cuh:50 -- glibc rand()/RAND_MAX fill through a host-visible pointer
+float *random_array(float *r, int L, int d, int N);

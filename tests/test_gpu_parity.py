@@ -1,0 +1,329 @@
+"""GPU parity tests: the HIP library, called through its C-ABI, against the CPU oracle.
+
+Bars: index mapping and the stencil bit-exact; dot products within 1 ulp-scale relative
+error of the oracle's double-accumulated value; float CG solutions within the reference's
+own acceptance (per-element abs 1e-3, tests.cu:14-41) and rel-L2 <= 1e-4 of the fp64
+solution; iteration counts within max(2, 5 %) of the fp32 CPU emulation of
+conjugate-gradient_gpu.cu:327-376.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def iters_close(a, b):
+    return abs(a - b) <= max(2, int(np.ceil(0.05 * max(a, b))))
+
+
+# ---- index mapping ---------------------------------------------------------------------
+
+def test_neighbour_index_known_answers(lib):
+    # main.jl:61-65
+    assert lib.neighbour_index_gpu(2, 1, 1, 3, 2, 9, 0) == 5
+    assert lib.neighbour_index_gpu(2, 0, 1, 3, 2, 9, 0) == 9
+    assert lib.neighbour_index_gpu(3, 0, -1, 3, 2, 9, 0) == 9
+
+
+# ---- dot product -----------------------------------------------------------------------
+
+def test_inner_product_ones_exact(lib):
+    # tests.cu:350-359
+    x = torch.ones(1000, dtype=torch.float32, device="cuda")
+    assert lib.inner_product_gpu(x.data_ptr(), x.data_ptr(), 1000) == 1000.0
+
+
+@pytest.mark.parametrize("n", [1, 3, 64, 1001, 4096, 1 << 20, (1 << 22) + 5])
+def test_inner_product_random(lib, oracle, n):
+    rng = np.random.default_rng(n)
+    v = rng.standard_normal(n).astype(np.float32)
+    w = rng.standard_normal(n).astype(np.float32)
+    got = lib.inner_product_gpu(dev(v).data_ptr(), dev(w).data_ptr(), n)
+    want = oracle.inner_product_f32(v, w)
+    scale = float(np.sum(np.abs(v.astype(np.float64) * w.astype(np.float64))))
+    # fp32 per-lane accumulation over a strided subset, then double: error << 1e-5 * sum|v w|
+    assert abs(got - want) <= 1e-5 * scale
+    # deterministic: same bits on a second call
+    assert lib.inner_product_gpu(dev(v).data_ptr(), dev(w).data_ptr(), n) == got
+
+
+def test_inner_product_host_pointer(lib):
+    v = np.arange(100, dtype=np.float32)
+    got = lib.inner_product_gpu(v.ctypes.data, v.ctypes.data, 100)
+    assert got == float(np.sum(v.astype(np.float64) ** 2))
+
+
+# ---- stencil ---------------------------------------------------------------------------
+
+STENCIL_CASES = [(1000, 1), (1024, 1), (4, 1), (10, 2), (5, 3), (64, 2), (256, 2), (12, 3), (16, 3), (32, 3),
+                 (8, 4), (6, 4), (4, 5), (2, 10), (260, 2), (100, 3)]
+
+
+@pytest.mark.parametrize("L,d", STENCIL_CASES)
+def test_stencil_bit_exact(lib, oracle, L, d):
+    N = L ** d
+    rng = np.random.default_rng(L * 31 + d)
+    u = rng.standard_normal(N).astype(np.float32)
+    want = oracle.laplace_f32(u, d, L)
+    ud = dev(u)
+    for mode in (0, 1):  # identical, as in the reference (tests.cu:477 vs gpu.cu:352)
+        out = torch.full((N,), np.nan, dtype=torch.float32, device="cuda")
+        lib.laplace_gpu_jl(out.data_ptr(), ud.data_ptr(), 0.5, d, L, N, mode, (N + 255) // 256, 256)
+        assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("L,d", [(10, 2), (64, 2), (8, 3)])
+def test_stencil_partial_launch_keeps_reference_meaning(lib, oracle, L, d):
+    """blocks*threads < N: only the first blocks*threads points are written (julia.cu:55-60)."""
+    N = L ** d
+    u = np.random.default_rng(5).standard_normal(N).astype(np.float32)
+    want = oracle.laplace_f32(u, d, L)
+    out = torch.full((N,), -7.0, dtype=torch.float32, device="cuda")
+    blocks, threads = 3, 8
+    lib.laplace_gpu_jl(out.data_ptr(), dev(u).data_ptr(), 0.0, d, L, N, 0, blocks, threads)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:24], want[:24]) and np.all(got[24:] == -7.0)
+
+
+@pytest.mark.parametrize("L,d", [(4, 2), (16, 2), (8, 3), (16, 3), (8, 4), (16, 4)])
+def test_stencil_morton_bit_exact(lib, oracle, L, d):
+    N = L ** d
+    u = np.random.default_rng(11).standard_normal(N).astype(np.float32)
+    want = oracle.laplace_morton_f32(u, d)
+    out = torch.zeros(N, dtype=torch.float32, device="cuda")
+    lib.laplace_gpu_jl(out.data_ptr(), dev(u).data_ptr(), 0.0, d, L, N, 2, (N + 255) // 256, 256)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_stencil_sin_and_square_reference_properties(lib):
+    """tests.cu:378-434: on 1-D sin(x) and x^2 the ratio / value is constant over the interior."""
+    N = 1000
+    step = np.float32(2 * np.pi / (N - 1))
+    xs = (-np.float32(np.pi) + np.arange(N, dtype=np.float32) * step).astype(np.float32)
+    for f, ratio in ((np.sin, True), (np.square, False)):
+        u = f(xs).astype(np.float32)
+        out = torch.zeros(N, dtype=torch.float32, device="cuda")
+        lib.laplace_gpu_jl(out.data_ptr(), dev(u).data_ptr(), 0.0, 1, N, N, 0, 4, 256)
+        r = out.cpu().numpy()
+        if ratio:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                r = r / u
+        assert np.all(np.abs(r[1:N - 1] - r[N // 2]) < 1e-3)
+
+
+# ---- CG --------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "cg_cpu_*.npz"))))
+def test_cg_recovers_golden_solution(lib, oracle, path):
+    """b from the reference's fixtures; the GPU float CG must recover x (tests.cu:466-501)."""
+    g = np.load(path)
+    L, d = int(g["L"]), int(g["d"])
+    N = L ** d
+    b = g["b"].astype(np.float32)
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    res, iters, hist = lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), x.data_ptr(), L, d, hist_len=200)
+    got = x.cpu().numpy()
+    assert np.all(np.abs(got - g["x"]) < 1e-3)
+    assert rel_l2(got, g["x_solved"]) <= 1e-4
+    # iteration count and printed history vs the fp32 CPU emulation of the reference loop
+    xe, rese, iterse, histe = oracle.cg_f32(b, L, d, hist_len=200)
+    assert iters_close(iters, iterse), (iters, iterse)
+    assert rel_l2(got, xe) <= 1e-4
+    n = min(iters, iterse, 10)
+    assert np.allclose(hist[:n], histe[:n], rtol=1e-3)
+    assert res == pytest.approx(hist[-1]) if iters else True
+
+
+@pytest.mark.parametrize("L,d,engine", [(64, 2, 1), (64, 2, 2), (16, 3, 1), (16, 3, 2), (8, 4, 1), (8, 4, 2),
+                                        (1024, 1, 1), (1024, 1, 2), (128, 2, 1)])
+def test_engines_agree_with_emulation(lib, oracle, L, d, engine):
+    N = L ** d
+    rng = np.random.default_rng(N)
+    xt = rng.random(N).astype(np.float32)
+    b = oracle.laplace_f32(xt, d, L)
+    s = lib.make_solver([L] * d, engine=engine)
+    assert s.engine == engine
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    bd = dev(b)
+    s.begin(bd.data_ptr(), x.data_ptr(), 1e-6, 1)
+    s.iterate(200, use_graph=(engine == 1))
+    iters, res, hist = s.finish(hist_len=200)
+    xe, rese, iterse, histe = oracle.cg_f32(b, L, d, hist_len=200)
+    assert iters_close(iters, iterse), (iters, iterse)
+    got = x.cpu().numpy()
+    if iterse < 200:
+        assert np.all(np.abs(got - xt) < 1e-3)
+    assert rel_l2(got, xe) <= 2e-4
+    s.close()
+
+
+def test_graph_and_plain_launches_are_bit_identical(lib, oracle):
+    L, d = 128, 2
+    N = L * L
+    b = np.random.default_rng(2).random(N).astype(np.float32)
+    outs = []
+    for use_graph in (True, False):
+        s = lib.make_solver([L, L])
+        x = torch.zeros(N, dtype=torch.float32, device="cuda")
+        bd = dev(b)
+        s.begin(bd.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.iterate(37, use_graph=use_graph)
+        s.iterate(13, use_graph=use_graph)
+        iters, res, hist = s.finish(hist_len=64)
+        assert iters == 50
+        outs.append((x.cpu().numpy(), np.array(hist)))
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_fixed_iteration_history_tracks_emulation(lib, oracle):
+    """A problem that cannot converge in 200 float iterations runs all 200 (gpu.cu:348)."""
+    L, d = 256, 2
+    N = L * L
+    b = np.random.default_rng(9).random(N).astype(np.float32)
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    res, iters, hist = lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), x.data_ptr(), L, d, hist_len=200)
+    xe, rese, iterse, histe = oracle.cg_f32(b, L, d, hist_len=200)
+    assert iters == iterse == 200
+    assert np.allclose(hist[:50], histe[:50], rtol=2e-3)
+    assert rel_l2(x.cpu().numpy(), xe) <= 1e-3
+
+
+def test_cg_accumulates_into_x_and_assumes_r_equals_b(lib, oracle):
+    """x is added to, not restarted from (gpu.cu:336,356): x_out = x_in + sum alpha p."""
+    L, d = 10, 2
+    g = np.load(os.path.join(GOLDEN, "cg_cpu_L10_d2.npz"))
+    b = g["b"].astype(np.float32)
+    x0 = np.full(100, 3.0, np.float32)
+    xa = dev(x0.copy())
+    xb = torch.zeros(100, dtype=torch.float32, device="cuda")
+    lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), xa.data_ptr(), L, d)
+    lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), xb.data_ptr(), L, d)
+    assert np.allclose(xa.cpu().numpy() - 3.0, xb.cpu().numpy(), atol=2e-6)
+
+
+def test_reference_entry_point_on_managed_fields(lib, capfd):
+    """main.cu:46-50 / tests.cu:472-488 usage: managed N+1 fields touched by the host."""
+    L, d, N = 10, 2, 100
+    g = np.load(os.path.join(GOLDEN, "cg_cpu_L10_d2.npz"))
+    pb = lib.c.cg_allocate_field(N)
+    px = lib.c.cg_allocate_field(N)
+    fb = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_float)), shape=(N + 1,))
+    fx = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_float)), shape=(N + 1,))
+    assert np.all(fb == 0) and np.all(fx == 0)
+    fb[:N] = g["b"].astype(np.float32)
+    res = lib.conjugate_gradient_gpu(pb, px, L, d)
+    C.CDLL(None).fflush(None)  # the library prints through C stdio
+    out = capfd.readouterr().out.strip().splitlines()
+    assert np.all(np.abs(fx[:N] - g["x"]) < 1e-3)
+    # the reference prints "i,residue" once per iteration (gpu.cu:369)
+    assert len(out) >= 1 and out[0].startswith("1,")
+    assert int(out[-1].split(",")[0]) == len(out)
+    assert float(out[-1].split(",")[1]) == pytest.approx(res, abs=1e-6)
+    lib.c.cg_free_field(pb)
+    lib.c.cg_free_field(px)
+
+
+@pytest.mark.parametrize("L,d", [(16, 2), (8, 3), (8, 4)])
+def test_morton_cg_equals_lexicographic_cg(lib, oracle, L, d):
+    N = L ** d
+    rng = np.random.default_rng(4)
+    xt = rng.random(N).astype(np.float32)
+    b = oracle.laplace_f32(xt, d, L)
+    perm = oracle.lex_to_morton_perm(L, d)
+    bm = np.zeros(N, np.float32)
+    bm[perm] = b
+    xl = torch.zeros(N, dtype=torch.float32, device="cuda")
+    xm = torch.zeros(N, dtype=torch.float32, device="cuda")
+    _, it_l, _ = lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), xl.data_ptr(), L, d, index_mode=0)
+    _, it_m, _ = lib.conjugate_gradient_gpu_ex(dev(bm).data_ptr(), xm.data_ptr(), L, d, index_mode=2)
+    assert iters_close(it_l, it_m)
+    assert np.all(np.abs(xm.cpu().numpy()[perm] - xt) < 1e-3)
+    assert rel_l2(xm.cpu().numpy()[perm], xl.cpu().numpy()) <= 1e-4
+
+
+def test_preconditioner_rule_stops_on_fresh_residual(lib, oracle):
+    """lagged = 0 reproduces the CPU preconditioner's stop rule (cpu.cu:299,317) in float."""
+    g = np.load(os.path.join(GOLDEN, "pcg_cpu_L50_d2.npz"))
+    b = g["b"].astype(np.float32)
+    x = torch.zeros(2500, dtype=torch.float32, device="cuda")
+    res, iters, _ = lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), x.data_ptr(), 50, 2, maxit=-1, rel=1e-3, lagged=0)
+    xe, rese, iterse, _ = oracle.cg_f32(b, 50, 2, maxit=-1, rel=1e-3, lagged=False)
+    assert iters_close(iters, iterse), (iters, iterse)
+    assert rel_l2(x.cpu().numpy(), xe) <= 1e-3
+
+
+def test_mixed_precision_matches_fp64_reference(lib, oracle):
+    """Double outer CG + float GPU inner CG recovers the reference's fp64 solution."""
+    g = np.load(os.path.join(GOLDEN, "pcg_cpu_L50_d2.npz"))
+    b = np.ascontiguousarray(g["b"], np.float64)
+    x = np.zeros(2500, np.float64)
+    outer, inner = lib.preconditioned_cg_gpu(b.ctypes.data, x.ctypes.data, 50, 2)
+    assert 1 <= outer <= 8 and len(inner) >= outer
+    assert np.all(np.abs(x - g["x"]) < 1e-3)          # tests.cu:114-146 acceptance
+    assert rel_l2(x, g["x_pcg"]) <= 1e-7              # outer tolerance is 1e-8 |b|
+    # a plain float solve cannot reach that
+    xf = torch.zeros(2500, dtype=torch.float32, device="cuda")
+    lib.conjugate_gradient_gpu_ex(dev(b.astype(np.float32)).data_ptr(), xf.data_ptr(), 50, 2)
+    assert rel_l2(xf.cpu().numpy(), g["x_pcg"]) > rel_l2(x, g["x_pcg"])
+
+
+# ---- size-independent properties at larger sizes ---------------------------------------
+
+@pytest.mark.parametrize("L,d", [(2048, 2), (128, 3), (32, 4)])
+def test_stencil_linearity_and_symmetry_large(lib, L, d):
+    """<A u, v> == <u, A v> and A(u+v) == A u + A v up to rounding, at sizes the oracle skips."""
+    N = L ** d
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    u = torch.rand(N, device="cuda", generator=gen)
+    v = torch.rand(N, device="cuda", generator=gen)
+    Au, Av, Auv = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+    uv = u + v
+    for src, dst in ((u, Au), (v, Av), (uv, Auv)):
+        lib.laplace_gpu_jl(dst.data_ptr(), src.data_ptr(), 0.0, d, L, N, 0, (N + 255) // 256, 256)
+    a = lib.inner_product_gpu(Au.data_ptr(), v.data_ptr(), N)
+    b = lib.inner_product_gpu(u.data_ptr(), Av.data_ptr(), N)
+    assert abs(a - b) <= 1e-4 * abs(a)
+    assert torch.allclose(Auv, Au + Av, rtol=0, atol=1e-4)
+    # against torch on the same data (fp32, different operation order)
+    t = u.reshape([L] * d)
+    ref = 2 * d * t.clone()
+    for ax in range(d):
+        ref -= torch.roll(t, 1, ax) * (torch.arange(L, device="cuda") > 0).reshape([-1 if i == ax else 1 for i in range(d)])
+        ref -= torch.roll(t, -1, ax) * (torch.arange(L, device="cuda") < L - 1).reshape([-1 if i == ax else 1 for i in range(d)])
+    assert torch.allclose(Au.reshape([L] * d), ref, rtol=0, atol=1e-4)
+
+
+def test_eigenmode_rhs_converges_in_few_iterations(lib):
+    """b = sum of m Laplacian eigenmodes: CG terminates in about m iterations at any N."""
+    L, d, m = 1024, 2, 3
+    N = L * L
+    ax = torch.arange(1, L + 1, device="cuda", dtype=torch.float64) * (np.pi / (L + 1))
+    b = torch.zeros(L, L, device="cuda", dtype=torch.float64)
+    for j in range(1, m + 1):
+        b += torch.outer(torch.sin(j * ax), torch.sin((j + 1) * ax))
+    bf = b.reshape(-1).float().contiguous()
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    res, iters, hist = lib.conjugate_gradient_gpu_ex(bf.data_ptr(), x.data_ptr(), L, d, hist_len=200)
+    assert iters <= m + 3, iters
+    Ax = torch.empty_like(x)
+    lib.laplace_gpu_jl(Ax.data_ptr(), x.data_ptr(), 0.0, d, L, N, 0, (N + 255) // 256, 256)
+    assert (Ax - bf).norm().item() <= 1e-4 * bf.norm().item()

@@ -1,0 +1,93 @@
+"""CPU-side tests of the product library: exports, host solver vs the oracle (no GPU calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol(pkg, lib):
+    hdr = open(os.path.join(ROOT, "include", "conjugate_gradient_gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b([a-z_][a-z_0-9A-Z]*)\s*\(", hdr)) - {"defined"}
+    declared = {n for n in declared if n.startswith(("cg_", "conjugate", "inner_", "neighbour", "strong_", "time_",
+                                                     "add_jl", "laplace_gpu_jl", "preconditioned"))}
+    assert declared == set(pkg.binding.EXPORTS)
+    for name in declared:
+        assert hasattr(lib.c, name), name
+
+
+def test_neighbour_index_host_entry_matches_oracle(lib, oracle):
+    for L, d in [(3, 2), (5, 2), (4, 3), (3, 4), (7, 1)]:
+        N = L ** d
+        for ind in range(N):
+            for k in range(d):
+                for a in (-1, 0, 1):
+                    want = oracle.neighbour_index_gpu(ind, k, a, L, d, N, 0)
+                    assert lib.neighbour_index_gpu(ind, k, a, L, d, N, 0) == want
+                    assert lib.neighbour_index_gpu(ind, k, a, L, d, N, 1) == want
+
+
+def test_neighbour_index_morton_mode(lib, oracle):
+    for L, d in [(4, 2), (8, 3), (4, 4)]:
+        N = L ** d
+        for ind in range(N):
+            for k in range(d):
+                for a in (-1, 1):
+                    nb = oracle.morton_neighbour(ind, d, k, a)
+                    want = nb if nb < N else N
+                    assert lib.neighbour_index_gpu(ind, k, a, L, d, N, 2) == want
+
+
+def test_u01_generator_host(lib):
+    v = np.array([lib.c.cg_u01_host(1234, i) for i in range(4096)], np.float32)
+    assert v.min() >= 0.0 and v.max() < 1.0
+    assert abs(v.mean() - 0.5) < 0.02 and abs(v.std() - 0.2887) < 0.02
+
+
+def _cpu_api(lib):
+    """C++-linkage host API of the product library (include/conjugate_gradient_cpu.h)."""
+    c = lib.c
+    dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    f = {}
+    f["minus_laplace"] = c["_Z13minus_laplacePdS_iii"]
+    f["minus_laplace"].argtypes = [dp, dp, C.c_int, C.c_int, C.c_int]
+    f["conjugate_gradient"] = c["_Z18conjugate_gradientPKdPdii"]
+    f["conjugate_gradient"].argtypes = [dp, dp, C.c_int, C.c_int]
+    f["conjugate_gradient"].restype = C.c_double
+    f["preconditioned_cg"] = c["_Z17preconditioned_cgPdS_ii"]
+    f["preconditioned_cg"].argtypes = [dp, dp, C.c_int, C.c_int]
+    f["preconditioned_cg"].restype = C.c_void_p
+    return f
+
+
+@pytest.mark.parametrize("name", ["cg_cpu_L5_d3", "cg_cpu_L10_d2", "cg_cpu_L64_d1", "cg_cpu_L8_d4"])
+def test_host_solver_bitwise_equals_reference_fixture(lib, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    L, d = int(g["L"]), int(g["d"])
+    N = L ** d
+    api = _cpu_api(lib)
+    x = np.zeros(N + 1)
+    x[:N] = g["x"]
+    b = np.zeros(N + 1)
+    api["minus_laplace"](b, x, d, L, N)
+    assert np.array_equal(b[:N], g["b"])
+    x0 = np.zeros(N + 1)
+    ret = api["conjugate_gradient"](b, x0, L, d)
+    assert ret == float(g["ret"]) and np.array_equal(x0[:N], g["x_solved"])
+
+
+def test_host_pcg_bitwise_equals_reference_fixture(lib, capfd):
+    g = np.load(os.path.join(GOLDEN, "pcg_cpu_L50_d2.npz"))
+    api = _cpu_api(lib)
+    b = np.zeros(2501)
+    b[:2500] = g["b"]
+    x = np.zeros(2501)
+    api["preconditioned_cg"](b, x, 50, 2)
+    assert np.array_equal(x[:2500], g["x_pcg"])
+    C.CDLL(None).fflush(None)  # the library prints through C stdio
+    out = capfd.readouterr().out
+    assert "number of steps (outer) 4" in out and out.count("number of steps inner") == 4
