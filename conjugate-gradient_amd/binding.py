@@ -50,6 +50,12 @@ class Library:
                 f"{path} is missing: build it with `make -C {PKG_DIR}` "
                 "(there is no fallback implementation)")
         self.path = path
+        # torch ships its own HIP runtime; when both live in one process it has to be the
+        # one already loaded, or device pointers from torch are foreign to this library
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.c = C.CDLL(path)
         c = self.c
         fp, vp, u32, i32 = C.c_void_p, C.c_void_p, C.c_uint, C.c_int

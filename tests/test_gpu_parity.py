@@ -56,13 +56,14 @@ def test_inner_product_random(lib, oracle, n):
     rng = np.random.default_rng(n)
     v = rng.standard_normal(n).astype(np.float32)
     w = rng.standard_normal(n).astype(np.float32)
-    got = lib.inner_product_gpu(dev(v).data_ptr(), dev(w).data_ptr(), n)
+    vd, wd = dev(v), dev(w)  # keep the tensors alive across the call
+    got = lib.inner_product_gpu(vd.data_ptr(), wd.data_ptr(), n)
     want = oracle.inner_product_f32(v, w)
     scale = float(np.sum(np.abs(v.astype(np.float64) * w.astype(np.float64))))
     # fp32 per-lane accumulation over a strided subset, then double: error << 1e-5 * sum|v w|
     assert abs(got - want) <= 1e-5 * scale
     # deterministic: same bits on a second call
-    assert lib.inner_product_gpu(dev(v).data_ptr(), dev(w).data_ptr(), n) == got
+    assert lib.inner_product_gpu(vd.data_ptr(), wd.data_ptr(), n) == got
 
 
 def test_inner_product_host_pointer(lib):
@@ -98,7 +99,8 @@ def test_stencil_partial_launch_keeps_reference_meaning(lib, oracle, L, d):
     want = oracle.laplace_f32(u, d, L)
     out = torch.full((N,), -7.0, dtype=torch.float32, device="cuda")
     blocks, threads = 3, 8
-    lib.laplace_gpu_jl(out.data_ptr(), dev(u).data_ptr(), 0.0, d, L, N, 0, blocks, threads)
+    ud = dev(u)
+    lib.laplace_gpu_jl(out.data_ptr(), ud.data_ptr(), 0.0, d, L, N, 0, blocks, threads)
     got = out.cpu().numpy()
     assert np.array_equal(got[:24], want[:24]) and np.all(got[24:] == -7.0)
 
@@ -109,7 +111,8 @@ def test_stencil_morton_bit_exact(lib, oracle, L, d):
     u = np.random.default_rng(11).standard_normal(N).astype(np.float32)
     want = oracle.laplace_morton_f32(u, d)
     out = torch.zeros(N, dtype=torch.float32, device="cuda")
-    lib.laplace_gpu_jl(out.data_ptr(), dev(u).data_ptr(), 0.0, d, L, N, 2, (N + 255) // 256, 256)
+    ud = dev(u)
+    lib.laplace_gpu_jl(out.data_ptr(), ud.data_ptr(), 0.0, d, L, N, 2, (N + 255) // 256, 256)
     assert np.array_equal(out.cpu().numpy(), want)
 
 
@@ -121,7 +124,8 @@ def test_stencil_sin_and_square_reference_properties(lib):
     for f, ratio in ((np.sin, True), (np.square, False)):
         u = f(xs).astype(np.float32)
         out = torch.zeros(N, dtype=torch.float32, device="cuda")
-        lib.laplace_gpu_jl(out.data_ptr(), dev(u).data_ptr(), 0.0, 1, N, N, 0, 4, 256)
+        ud = dev(u)
+        lib.laplace_gpu_jl(out.data_ptr(), ud.data_ptr(), 0.0, 1, N, N, 0, 4, 256)
         r = out.cpu().numpy()
         if ratio:
             with np.errstate(divide="ignore", invalid="ignore"):
@@ -139,7 +143,8 @@ def test_cg_recovers_golden_solution(lib, oracle, path):
     N = L ** d
     b = g["b"].astype(np.float32)
     x = torch.zeros(N, dtype=torch.float32, device="cuda")
-    res, iters, hist = lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), x.data_ptr(), L, d, hist_len=200)
+    bd = dev(b)
+    res, iters, hist = lib.conjugate_gradient_gpu_ex(bd.data_ptr(), x.data_ptr(), L, d, hist_len=200)
     got = x.cpu().numpy()
     assert np.all(np.abs(got - g["x"]) < 1e-3)
     assert rel_l2(got, g["x_solved"]) <= 1e-4
@@ -200,7 +205,8 @@ def test_fixed_iteration_history_tracks_emulation(lib, oracle):
     N = L * L
     b = np.random.default_rng(9).random(N).astype(np.float32)
     x = torch.zeros(N, dtype=torch.float32, device="cuda")
-    res, iters, hist = lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), x.data_ptr(), L, d, hist_len=200)
+    bd = dev(b)
+    res, iters, hist = lib.conjugate_gradient_gpu_ex(bd.data_ptr(), x.data_ptr(), L, d, hist_len=200)
     xe, rese, iterse, histe = oracle.cg_f32(b, L, d, hist_len=200)
     assert iters == iterse == 200
     assert np.allclose(hist[:50], histe[:50], rtol=2e-3)
@@ -215,8 +221,9 @@ def test_cg_accumulates_into_x_and_assumes_r_equals_b(lib, oracle):
     x0 = np.full(100, 3.0, np.float32)
     xa = dev(x0.copy())
     xb = torch.zeros(100, dtype=torch.float32, device="cuda")
-    lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), xa.data_ptr(), L, d)
-    lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), xb.data_ptr(), L, d)
+    bd = dev(b)
+    lib.conjugate_gradient_gpu_ex(bd.data_ptr(), xa.data_ptr(), L, d)
+    lib.conjugate_gradient_gpu_ex(bd.data_ptr(), xb.data_ptr(), L, d)
     assert np.allclose(xa.cpu().numpy() - 3.0, xb.cpu().numpy(), atol=2e-6)
 
 
@@ -253,8 +260,9 @@ def test_morton_cg_equals_lexicographic_cg(lib, oracle, L, d):
     bm[perm] = b
     xl = torch.zeros(N, dtype=torch.float32, device="cuda")
     xm = torch.zeros(N, dtype=torch.float32, device="cuda")
-    _, it_l, _ = lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), xl.data_ptr(), L, d, index_mode=0)
-    _, it_m, _ = lib.conjugate_gradient_gpu_ex(dev(bm).data_ptr(), xm.data_ptr(), L, d, index_mode=2)
+    bd, bmd = dev(b), dev(bm)
+    _, it_l, _ = lib.conjugate_gradient_gpu_ex(bd.data_ptr(), xl.data_ptr(), L, d, index_mode=0)
+    _, it_m, _ = lib.conjugate_gradient_gpu_ex(bmd.data_ptr(), xm.data_ptr(), L, d, index_mode=2)
     assert iters_close(it_l, it_m)
     assert np.all(np.abs(xm.cpu().numpy()[perm] - xt) < 1e-3)
     assert rel_l2(xm.cpu().numpy()[perm], xl.cpu().numpy()) <= 1e-4
@@ -265,7 +273,8 @@ def test_preconditioner_rule_stops_on_fresh_residual(lib, oracle):
     g = np.load(os.path.join(GOLDEN, "pcg_cpu_L50_d2.npz"))
     b = g["b"].astype(np.float32)
     x = torch.zeros(2500, dtype=torch.float32, device="cuda")
-    res, iters, _ = lib.conjugate_gradient_gpu_ex(dev(b).data_ptr(), x.data_ptr(), 50, 2, maxit=-1, rel=1e-3, lagged=0)
+    bd = dev(b)
+    res, iters, _ = lib.conjugate_gradient_gpu_ex(bd.data_ptr(), x.data_ptr(), 50, 2, maxit=-1, rel=1e-3, lagged=0)
     xe, rese, iterse, _ = oracle.cg_f32(b, 50, 2, maxit=-1, rel=1e-3, lagged=False)
     assert iters_close(iters, iterse), (iters, iterse)
     assert rel_l2(x.cpu().numpy(), xe) <= 1e-3
@@ -282,7 +291,8 @@ def test_mixed_precision_matches_fp64_reference(lib, oracle):
     assert rel_l2(x, g["x_pcg"]) <= 1e-7              # outer tolerance is 1e-8 |b|
     # a plain float solve cannot reach that
     xf = torch.zeros(2500, dtype=torch.float32, device="cuda")
-    lib.conjugate_gradient_gpu_ex(dev(b.astype(np.float32)).data_ptr(), xf.data_ptr(), 50, 2)
+    bf = dev(b.astype(np.float32))
+    lib.conjugate_gradient_gpu_ex(bf.data_ptr(), xf.data_ptr(), 50, 2)
     assert rel_l2(xf.cpu().numpy(), g["x_pcg"]) > rel_l2(x, g["x_pcg"])
 
 
