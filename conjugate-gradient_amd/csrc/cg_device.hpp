@@ -398,6 +398,10 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
         }
       }
 
+      // lanes past the end of the row hold zeros but see their neighbour's edge value
+      if (!act)
+        lv = zero4;
+
       if constexpr (MODE == MODE_STENCIL)
       {
         if (act)

@@ -323,17 +323,41 @@ def test_stencil_linearity_and_symmetry_large(lib, L, d):
 
 
 def test_eigenmode_rhs_converges_in_few_iterations(lib):
-    """b = sum of m Laplacian eigenmodes: CG terminates in about m iterations at any N."""
-    L, d, m = 1024, 2, 3
+    """b = sum of m mid-spectrum Laplacian eigenmodes: CG terminates after m iterations (+1 for
+    the lagged test) at any grid size.  (Low modes do not show this in fp32: their eigenvalues
+    are ~1e-3 and rounding in A p swamps them; the fp32 CPU emulation behaves the same.)"""
+    L, d = 1024, 2
     N = L * L
     ax = torch.arange(1, L + 1, device="cuda", dtype=torch.float64) * (np.pi / (L + 1))
     b = torch.zeros(L, L, device="cuda", dtype=torch.float64)
-    for j in range(1, m + 1):
-        b += torch.outer(torch.sin(j * ax), torch.sin((j + 1) * ax))
+    for j in (L // 4, L // 2, 3 * L // 4):
+        b += torch.outer(torch.sin(j * ax), torch.sin(j * ax))
     bf = b.reshape(-1).float().contiguous()
     x = torch.zeros(N, dtype=torch.float32, device="cuda")
     res, iters, hist = lib.conjugate_gradient_gpu_ex(bf.data_ptr(), x.data_ptr(), L, d, hist_len=200)
-    assert iters <= m + 3, iters
+    assert iters == 4, (iters, hist)
     Ax = torch.empty_like(x)
     lib.laplace_gpu_jl(Ax.data_ptr(), x.data_ptr(), 0.0, d, L, N, 0, (N + 255) // 256, 256)
-    assert (Ax - bf).norm().item() <= 1e-4 * bf.norm().item()
+    assert (Ax - bf).norm().item() <= 1e-5 * bf.norm().item()
+
+
+@pytest.mark.parametrize("L,d", [(2048, 2), (128, 3)])
+def test_recurrence_residual_equals_true_residual_large(lib, L, d):
+    """After K iterations the solver's r (updated by recurrence) must equal b - A x recomputed from x."""
+    N = L ** d
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    b = torch.rand(N, device="cuda", generator=gen)
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    s = lib.make_solver([L] * d)
+    s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+    s.iterate(41)
+    iters, res, hist = s.finish(hist_len=64)
+    assert iters == 41 and len(hist) == 41
+    assert all(np.isfinite(hist)) and hist[0] == pytest.approx(b.double().norm().item(), rel=1e-6)
+    r_ptr = lib.c.cg_solver_r(s.h)
+    rec = np.sqrt(lib.inner_product_gpu(r_ptr, r_ptr, N))
+    Ax = torch.empty_like(x)
+    lib.laplace_gpu_jl(Ax.data_ptr(), x.data_ptr(), 0.0, d, L, N, 0, (N + 255) // 256, 256)
+    true_res = (b.double() - Ax.double()).norm().item()
+    assert abs(true_res - rec) <= 1e-3 * rec, (true_res, rec)
+    s.close()
