@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused Laplace-CG iteration on MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one CG iteration (kernel A + kernel B) over the whole grid.  Workload at every N:
+each GPU owns an 8192 x 8192 float slab (2^26 points, config "2D Laplace 8192^2 float CG");
+with N > 1 the slabs stack along axis 1 into an 8192 x (8192 N) grid (weak scaling) with one
+halo row of r and two scalar all-reduces per iteration over RCCL.  Synthetic data: b = u01
+(counter-based generator, seed 1234), x0 = 0; float CG cannot converge on this grid within
+any practical count, so every step does full work (the stop tolerance is set to 0).
+
+value = slab-iterations per second summed over ranks (= CG iterations/s at N = 1).
+roofline: algorithmic HBM bytes of the dominant kernel (B: 24 B/point) over its mean
+duration measured with HIP events on the solver's stream.  cpu_baseline: the oracle's
+restatement of the reference CPU solver (fp64, one core) on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
+BYTES_A, BYTES_B = 20, 24       # algorithmic bytes/point: A = stencil+dot (8) + p update (12); B = x,r update + dot
+BYTES_ITER = 44
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="2d-8192", help="2d-8192 | 3d-1024x128 | 3d-512 | 4d-128-morton | LxLx..[:mode]")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def workload_extents(name):
+    mode = 0
+    if name == "2d-8192":
+        ext = [8192, 8192]
+    elif name == "3d-1024x128":
+        ext = [1024, 1024, 128]
+    elif name == "3d-512":
+        ext = [512, 512, 512]
+    elif name == "4d-128-morton":
+        ext, mode = [128] * 4, 2
+    else:
+        spec, _, m = name.partition(":")
+        ext = [int(v) for v in spec.split("x")]
+        mode = int(m) if m else 0
+    return ext, mode
+
+
+def cpu_baseline(ext, budget_s):
+    """Oracle restatement of conjugate_gradient (cpu.cu:216-261), fp64, 1 thread, -O3 -march=native.
+    Bounded sample: a square/cubic sub-grid of the workload's dimension sized so the run takes
+    roughly budget_s; iterations/s is scaled to the workload's point count (cost is linear in
+    points: the stencil's index arithmetic dominates)."""
+    import numpy as np
+    from oracle import oracle as orc
+    o = orc.Oracle(native=True)
+    d = len(ext)
+    n_full = 1
+    for e in ext:
+        n_full *= e
+    # calibrate on a small grid, then pick the sample size
+    Ls = {1: 1 << 16, 2: 256, 3: 40, 4: 16}.get(d, 8)
+    b = np.random.default_rng(0).random(Ls ** d)
+    t0 = time.perf_counter()
+    o.conjugate_gradient(b, Ls, d, max_iters=2)
+    per_pt_it = (time.perf_counter() - t0) / (2.5 * Ls ** d)   # setup ~ half an iteration
+    iters = 4
+    pts = budget_s / (per_pt_it * (iters + 0.5))
+    L = max(Ls, int(pts ** (1.0 / d)))
+    L = min(L, min(ext))
+    n = L ** d
+    b = np.random.default_rng(1).random(n)
+    t0 = time.perf_counter()
+    _, _, done, _ = o.conjugate_gradient(b, L, d, max_iters=iters)
+    dt = time.perf_counter() - t0
+    its_per_s_sample = done / dt
+    return {"value": its_per_s_sample * n / n_full, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{done} fp64 CG iterations on a {L}^{d} grid ({n} points, {dt:.1f} s), "
+                      f"scaled by points to the {'x'.join(map(str, ext))} workload"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    pkg = load_package()
+    lib = pkg.load_library()
+    ext, mode = workload_extents(args.workload)
+    N = 1
+    for e in ext:
+        N *= e
+
+    b = torch.empty(N, dtype=torch.float32, device=device)
+    x = torch.zeros(N, dtype=torch.float32, device=device)
+    # rank-distinct synthetic right-hand side: one global u01 stream cut into slabs
+    lib.c.cg_fill_uniform(C.c_void_p(b.data_ptr()), N, 1234 + rank)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    roof = None
+    if world == 1:
+        s = lib.make_solver(ext, index_mode=mode)
+        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.iterate(args.warmup, use_graph=not args.no_graph)
+        s.sync()
+        barrier()
+        t0 = time.perf_counter()
+        s.iterate(args.steps, use_graph=not args.no_graph)
+        s.sync()
+        barrier()
+        dt = time.perf_counter() - t0
+        done, res, _ = s.finish()
+        assert done == args.warmup + args.steps, (done, args.warmup, args.steps)
+        # per-kernel device time, HIP events on the solver's stream, outside the timed region
+        msA, msB = s.time_kernels(max(10, min(50, args.steps)))
+        gA = BYTES_A * N / (msA * 1e-3) / 1e9
+        gB = BYTES_B * N / (msB * 1e-3) / 1e9
+        dom = ("B", msB, gB, BYTES_B) if msB >= msA else ("A", msA, gA, BYTES_A)
+        roof = {"bound": "hbm", "kernel": f"k_rows<MODE_{dom[0]}>" if s.engine == 1 else f"k_scalar<MODE_{dom[0]}>",
+                "achieved": round(dom[2], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(dom[2] / HBM_PEAK_GBPS, 4), "traffic": None,
+                "algorithmic_bytes_per_point": dom[3], "ms_per_launch": round(dom[1], 5),
+                "other_kernel": {"ms_per_launch": round(msA if dom[0] == "B" else msB, 5),
+                                 "achieved": round(gA if dom[0] == "B" else gB, 1)}}
+        parallelism = "single"
+    else:
+        from conjugate_gradient_amd.slab import SlabCG
+        s = SlabCG(lib, ext, rank=rank, world=world, device=device)
+        s.begin(b, x, 0.0, 1)
+        s.iterate(args.warmup)
+        s.sync()
+        barrier()
+        t0 = time.perf_counter()
+        s.iterate(args.steps)
+        s.sync()
+        barrier()
+        dt = time.perf_counter() - t0
+        done, res, _ = s.finish()
+        assert done == args.warmup + args.steps, (done, args.warmup, args.steps)
+        parallelism = f"slab{world}"
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        its = args.steps / dt
+        out = {
+            "metric": "cg_iterations_per_sec", "value": round(its * world, 3),
+            "unit": "CG iterations/s per 2^%d-point slab, summed over GPUs" % (N.bit_length() - 1)
+                    if (N & (N - 1)) == 0 else "CG iterations/s per slab, summed over GPUs",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "local_extents": ext, "index_mode": mode,
+                       "points_per_gpu": N, "parallelism": parallelism, "graph": not args.no_graph,
+                       "rhs": "u01 seed 1234+rank", "x0": 0},
+            "iterations_per_sec_global": round(its, 3),
+            "hbm_algorithmic_GBps": round(BYTES_ITER * N * world * its / 1e9, 1),
+            "hbm_frac_of_peak": round(BYTES_ITER * N * its / 1e9 / HBM_PEAK_GBPS, 4),
+            "final_residue": res,
+        }
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ext, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

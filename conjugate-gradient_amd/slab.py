@@ -1,0 +1,156 @@
+"""Slab-decomposed CG across ranks: one process per GPU, torch.distributed (RCCL over xGMI).
+
+The grid is cut along its slowest axis into contiguous slabs, one per rank.  Per CG
+iteration the ranks exchange
+
+  * one hyperplane of r with each neighbour (the only vector whose neighbours' values are
+    needed: kernel A rebuilds p = r + beta*p on its ghost planes locally), and
+  * two scalars, p.Ap and r.r, by all-reduce of device doubles; alpha and beta are then
+    derived on every rank's device from identical bits, so all ranks take the same path.
+
+Everything is enqueued asynchronously on the current stream; the host never waits inside
+the loop.  The compute steps are the HIP library's kernels (binding.Solver); a different
+`make_ops` can be injected so that the exchange logic can be exercised on CPU tensors with
+the gloo backend.
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+
+
+class HipSlabOps:
+    """The compute steps of one slab on the GPU: thin calls into libconjugate_gradient_gpu.so."""
+
+    def __init__(self, lib, extents, has_lo, has_hi, device):
+        self.lib = lib
+        self.device = device
+        desc = lib.desc(extents, 0, has_lo, has_hi)
+        self.buffer_len = lib.c.cg_solver_buffer_len(desc)
+        self.ghost_offset = lib.c.cg_solver_ghost_offset(desc)
+        self.plane = lib.c.cg_solver_plane(desc)
+        self.r_buf = torch.zeros(self.buffer_len, dtype=torch.float32, device=device)
+        self.p0_buf = torch.zeros(self.buffer_len, dtype=torch.float32, device=device)
+        self.p1_buf = torch.zeros(self.buffer_len, dtype=torch.float32, device=device)
+        self.dots = torch.zeros(2, dtype=torch.float64, device=device)  # [p.Ap, r.r]
+        # kernels and collectives share one non-default stream: torch orders its RCCL work
+        # against the stream that is current when a collective is issued
+        self.stream = torch.cuda.Stream(device)
+        torch.cuda.synchronize(device)
+        self.solver = lib.make_solver(extents, 0, has_lo, has_hi, stream=self.stream.cuda_stream,
+                                      r_buf=self.r_buf.data_ptr(), p0_buf=self.p0_buf.data_ptr(),
+                                      p1_buf=self.p1_buf.data_ptr())
+        self.solver.bind_sums(self.dots[0:1].data_ptr(), self.dots[1:2].data_ptr())
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
+
+    def begin_local(self, b, x):
+        # b and x were produced on the caller's (default) stream
+        self.stream.wait_stream(torch.cuda.default_stream(self.device))
+        self.solver.begin_local(b.data_ptr(), x.data_ptr())
+
+    def reduce(self, which):
+        self.solver.reduce(which, self.dots[which:which + 1].data_ptr())
+
+    def init_state(self, rel, lagged, maxit):
+        self.solver.init_state(rel, lagged, maxit)
+
+    def add_iterations(self, n):
+        self.solver.add_iterations(n)
+
+    def kernel_A(self):
+        self.solver.kernel_A()
+
+    def kernel_B(self):
+        self.solver.kernel_B()
+
+    def finish(self, hist_len=0):
+        return self.solver.finish(hist_len)
+
+    def sync(self):
+        self.solver.sync()
+
+
+class SlabCG:
+    """CG on this rank's slab of an extents[0] x ... x (sum of slab heights) grid.
+
+    extents: this rank's local extents (axis 0 contiguous, last axis = slab axis).
+    """
+
+    def __init__(self, lib, extents, rank=None, world=None, group=None, device=None, make_ops=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.extents = [int(e) for e in extents]
+        if len(self.extents) < 2 and self.world > 1:
+            raise ValueError("slab decomposition needs d >= 2")
+        self.has_lo = self.rank > 0
+        self.has_hi = self.rank < self.world - 1
+        self.N = 1
+        for e in self.extents:
+            self.N *= e
+        if make_ops is None:
+            if lib is None:
+                raise RuntimeError("SlabCG needs the HIP library (no fallback)")
+            self.ops = HipSlabOps(lib, self.extents, int(self.has_lo), int(self.has_hi), device)
+        else:
+            self.ops = make_ops(self.extents, int(self.has_lo), int(self.has_hi))
+        o = self.ops
+        g, n, pl = o.ghost_offset, self.N, o.plane
+        # views used by the halo exchange
+        self.r_ghost_lo = o.r_buf[g - pl:g]
+        self.r_first = o.r_buf[g:g + pl]
+        self.r_last = o.r_buf[g + n - pl:g + n]
+        self.r_ghost_hi = o.r_buf[g + n:g + n + pl]
+
+    # -- communication ------------------------------------------------------------------
+    def _global_rank(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def exchange_r(self):
+        """Boundary planes of r to the neighbours' ghost planes (both directions at once)."""
+        if self.world == 1:
+            return
+        ops = []
+        if self.has_lo:
+            ops.append(dist.P2POp(dist.isend, self.r_first, self._global_rank(self.rank - 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, self.r_ghost_lo, self._global_rank(self.rank - 1), self.group))
+        if self.has_hi:
+            ops.append(dist.P2POp(dist.isend, self.r_last, self._global_rank(self.rank + 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, self.r_ghost_hi, self._global_rank(self.rank + 1), self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def allreduce(self, which):
+        self.ops.reduce(which)
+        if self.world > 1:
+            dist.all_reduce(self.ops.dots[which:which + 1], op=dist.ReduceOp.SUM, group=self.group)
+
+    # -- solve --------------------------------------------------------------------------
+    def _ctx(self):
+        return self.ops.stream_ctx() if hasattr(self.ops, "stream_ctx") else contextlib.nullcontext()
+
+    def begin(self, b, x, rel=1e-6, lagged=1):
+        """b, x: this rank's slab (N floats each).  r = b, p = 0, global r.r, ghost planes of r."""
+        with self._ctx():
+            self.ops.begin_local(b, x)
+            self.allreduce(1)
+            self.ops.init_state(rel, lagged, 0)
+            self.exchange_r()
+
+    def iterate(self, n):
+        with self._ctx():
+            self.ops.add_iterations(n)
+            for _ in range(n):
+                self.ops.kernel_A()
+                self.allreduce(0)
+                self.ops.kernel_B()
+                self.allreduce(1)
+                self.exchange_r()
+
+    def finish(self, hist_len=0):
+        return self.ops.finish(hist_len)
+
+    def sync(self):
+        self.ops.sync()
