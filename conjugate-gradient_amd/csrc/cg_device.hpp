@@ -90,8 +90,9 @@ struct RowsGeom
 {
   int d;
   unsigned n0, n1;
-  unsigned nxc, ty, nstrips;
-  unsigned long long ntiles;
+  unsigned nxc;    // columns per row of axis 0
+  unsigned bpc;    // segments per column
+  unsigned nitems; // columns * bpc
   unsigned nk[CG_ROWS_MAXD];
   unsigned long long sk[CG_ROWS_MAXD];
   int has_lo, has_hi;
@@ -117,21 +118,36 @@ __device__ __forceinline__ double wave_sum(double v)
   return v;
 }
 
-// Sum of src[0..n) handed to every thread of the workgroup.  Wave 0 does the work in an
-// order that depends only on n, so every workgroup of every launch shape gets the same bits.
+// Sum of src[0..n) handed to every thread of the workgroup, the same bits for every
+// workgroup shape: 256 virtual lanes each sum a strided subset (8 loads in flight at a
+// time), four virtual waves are butterfly-reduced, and their totals are added in a fixed
+// order.  A workgroup with fewer than four waves lets each wave play several virtual ones.
 __device__ __forceinline__ double block_read_sum(const double *__restrict__ src, int n, double *sh)
 {
-  if (threadIdx.x < 64)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  for (int vw = wave; vw < 4; vw += nw)
   {
+    const int v = vw * 64 + lane;
     double s = 0;
-    for (int i = threadIdx.x; i < n; i += 64)
-      s += src[i];
+    for (int i0 = 0; i0 < n; i0 += 2048)
+    {
+      double t[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+      {
+        const int i = i0 + v + 256 * j;
+        t[j] = i < n ? src[i] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        s += t[j];
+    }
     s = wave_sum(s);
-    if (threadIdx.x == 0)
-      sh[0] = s;
+    if (lane == 0)
+      sh[vw] = s;
   }
   __syncthreads();
-  double v = sh[0];
+  const double v = ((sh[0] + sh[1]) + sh[2]) + sh[3];
   __syncthreads();
   return v;
 }
@@ -208,27 +224,79 @@ __device__ __forceinline__ IterCtl prologue_B(const VecArgs &a, double *sh)
   return c;
 }
 
+// ---- cache policy ------------------------------------------------------------------------
+//
+// MI355X has a 256 MiB memory-side Infinity Cache.  Loads and stores issued with the
+// non-temporal hint stream past it; everything else allocates in it.  POL_KEEP_R issues
+// every stream of the iteration non-temporally except the loads of r: r is touched three
+// times per iteration (read and written by kernel B, read by kernel A), so a grid whose r
+// fits the cache re-reads and re-writes it on-die and HBM carries 5 instead of 8 words per
+// point.  POL_PLAIN uses ordinary accesses throughout.
+enum
+{
+  POL_PLAIN = 0,
+  POL_KEEP_R = 1
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ float4 load4(const float *p)
+{
+  if constexpr (NT)
+  {
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+  }
+  else
+    return *reinterpret_cast<const float4 *>(p);
+}
+
+template <bool NT>
+__device__ __forceinline__ float load1(const float *p)
+{
+  if constexpr (NT)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+
+template <bool NT>
+__device__ __forceinline__ void store4(float *p, float4 v)
+{
+  if constexpr (NT)
+  {
+    const v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(p));
+  }
+  else
+    *reinterpret_cast<float4 *>(p) = v;
+}
+
 // ---- the stencil input of each mode ----------------------------------------------------
 
-template <int MODE>
+template <int MODE, int POL>
 struct Src
 {
+  // p streams past the cache under POL_KEEP_R (in every mode but the plain stencil, whose
+  // input is re-read by neighbouring rows of other workgroups); r is what the cache keeps
+  static constexpr bool NT_P = (POL == POL_KEEP_R) && (MODE != MODE_STENCIL);
   const float *__restrict__ p;
   const float *__restrict__ r;
   float beta;
   __device__ __forceinline__ float ld1(long long i) const
   {
-    float v = p[i];
+    float v = load1<NT_P>(p + i);
     if constexpr (MODE == MODE_A)
-      v = fmaf(beta, v, r[i]);
+      v = fmaf(beta, v, load1<false>(r + i));
     return v;
   }
   __device__ __forceinline__ float4 ld4(long long i) const
   {
-    float4 v = *reinterpret_cast<const float4 *>(p + i);
+    float4 v = load4<NT_P>(p + i);
     if constexpr (MODE == MODE_A)
     {
-      const float4 q = *reinterpret_cast<const float4 *>(r + i);
+      const float4 q = load4<false>(r + i);
       v.x = fmaf(beta, v.x, q.x);
       v.y = fmaf(beta, v.y, q.y);
       v.z = fmaf(beta, v.z, q.z);
@@ -244,16 +312,31 @@ __device__ __forceinline__ float axis_term(float up, float c, float um) { return
 
 // ---- rows engine -----------------------------------------------------------------------
 //
-// A tile is (4*blockDim.x points of axis 0) x (ty rows of axis 1) at fixed higher
-// coordinates.  GHOST: the vectors own one extra hyperplane below and above the last
-// axis (zero on a global face, the neighbour rank's data on a slab face, has_lo/has_hi).
+// Work item = (column, segment): a column is 4*blockDim.x consecutive points of axis 0 at
+// fixed coordinates of axes >= 2; a segment is a run of rows (axis 1) of that column.  The
+// host cuts every column into bpc near-equal segments so that the number of items matches
+// the number of workgroups the chip holds at once (no second, partial round of workgroups).
+// A workgroup marches down its segment with rows y-1, y, y+1 of the stencil input in
+// registers; the loads of row y+2 (and of x, r for row y+1) are issued before row y is
+// computed, so two rows' worth of bytes per lane are in flight.
+// Loads are never predicated: out-of-range rows and lanes are redirected to a valid
+// address and the value replaced by zero afterwards.
+// GHOST: the vectors own one extra hyperplane below and above the last axis (zero on a
+// global face, the neighbour rank's data on a slab face, has_lo/has_hi).
+// D: compile-time dimension (1..3), 0 = run-time g.d (>= 4).
 
-template <int MODE, bool GHOST>
+__device__ __forceinline__ float4 sel4(bool c, float4 v)
+{
+  return c ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+template <int MODE, bool GHOST, int D, int POL>
 __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
 {
   __shared__ double sh[8];
   const int tid = threadIdx.x, lane = tid & 63;
-  Src<MODE> src;
+  constexpr bool NT = POL == POL_KEEP_R; // x, the stores of r and of p_new
+  Src<MODE, POL> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
   if constexpr (MODE == MODE_A)
@@ -281,80 +364,98 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
   const float alpha = coef;
   float acc = 0;
   const float4 zero4 = make_float4(0, 0, 0, 0);
+  const int d = D > 0 ? D : g.d;
   const long long n0 = g.n0;
-  const bool rowghost = GHOST && g.d == 2;
+  const long long n1 = g.n1;
+  // axis 1 is the ghosted (last) axis only in 2-D
+  const bool rowghost = GHOST && d == 2;
 
-  for (unsigned long long tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x)
+  for (unsigned item = blockIdx.x; item < g.nitems; item += gridDim.x)
   {
-    unsigned long long t = tile;
-    const unsigned xc = (unsigned)(t % g.nxc);
-    t /= g.nxc;
-    const unsigned ys = (unsigned)(t % g.nstrips);
-    t /= g.nstrips;
+    const unsigned seg = item % g.bpc;
+    const unsigned col = item / g.bpc;
+    const unsigned xc = col % g.nxc;
+    unsigned hi = col / g.nxc;
     long long base = 0;
     unsigned okm = 0, okp = 0;
     bool st_lo = false, st_hi = false;
-    for (int k = 2; k < g.d; k++)
+    for (int k = 2; k < d; k++)
     {
       const unsigned nk = g.nk[k - 2];
-      const unsigned ck = (unsigned)(t % nk);
-      t /= nk;
+      const unsigned ck = hi % nk;
+      hi /= nk;
       base += (long long)ck * (long long)g.sk[k - 2];
-      const bool last = GHOST && (k == g.d - 1);
-      if (ck > 0 || (last && g.has_lo))
+      const bool last = GHOST && (k == d - 1);
+      // ghost planes exist in memory and hold zeros on a global face
+      if (ck > 0 || last)
         okm |= 1u << (k - 2);
-      if (ck + 1 < nk || (last && g.has_hi))
+      if (ck + 1 < nk || last)
         okp |= 1u << (k - 2);
       if (last && ck == 0 && g.has_lo)
         st_lo = true;
       if (last && ck + 1 == nk && g.has_hi)
         st_hi = true;
     }
+    const long long y0 = (long long)((unsigned long long)seg * g.n1 / g.bpc);
+    const long long y1 = (long long)((unsigned long long)(seg + 1) * g.n1 / g.bpc);
+    if (y0 >= y1)
+      continue;
     const unsigned x0 = (xc * blockDim.x + tid) * 4u;
     const bool act = x0 < g.n0;
-    const unsigned y0 = ys * g.ty;
-    const unsigned y1 = min(y0 + g.ty, g.n1);
-    long long idx = base + (long long)y0 * n0 + x0;
+    const long long col0 = base + (act ? x0 : g.n0 - 4u);
     const bool el = act && lane == 0 && x0 > 0;
     const bool er = act && lane == 63 && x0 + 4 < g.n0;
     const bool edge = el || er;
     const long long eoff = (lane == 0) ? -1 : 4;
     const bool rightmost = (lane == 63) || (x0 + 4 >= g.n0);
 
-    float4 pm = zero4, pc = zero4, pn;
-    float ec = 0, en;
-    if (act && (y0 > 0 || (rowghost && g.has_lo)))
-      pm = src.ld4(idx - n0);
-    if (act)
-      pc = src.ld4(idx);
-    if (edge)
-      ec = src.ld1(idx + eoff);
+    // stencil input of row yy (a zero row outside the grid unless it is a ghost row)
+    auto ldrow = [&](long long yy) -> float4 {
+      const bool ok = rowghost || (yy >= 0 && yy < n1);
+      const float4 v = src.ld4(col0 + (ok ? yy : y0) * n0);
+      return sel4(ok, v);
+    };
+    // the element just outside this wave's span of row yy (rows inside the grid only)
+    auto ldedge = [&](long long yy) -> float {
+      float e = 0.0f;
+      if (edge)
+        e = src.ld1(col0 + yy * n0 + eoff);
+      return e;
+    };
+
+    float4 pm = ldrow(y0 - 1);
+    float4 pc = ldrow(y0);
+    float4 pn = ldrow(y0 + 1);
+    float ec = ldedge(y0);
+    float en = ldedge(y0 + 1 < y1 ? y0 + 1 : y0);
+    float4 xv = zero4, rv = zero4;
+    if constexpr (MODE == MODE_B)
+    {
+      xv = load4<NT>(a.x + col0 + y0 * n0);
+      rv = load4<false>(a.r + col0 + y0 * n0);
+    }
     if constexpr (MODE == MODE_A)
     {
       if (rowghost && g.has_lo && y0 == 0 && act)
-        *reinterpret_cast<float4 *>(p_new + idx - n0) = pm;
+        store4<NT>(p_new + col0 - n0, pm);
     }
 
-    for (unsigned y = y0; y < y1; y++, idx += n0)
+    for (long long y = y0; y < y1; y++)
     {
-      float4 xv, rv;
+      const long long idx = col0 + y * n0;
+      // ---- prefetch for the next row -------------------------------------------------
+      const long long y2 = y + 2 <= y1 ? y + 2 : y1;       // row y1 is the last one ever needed
+      const float4 pnn = ldrow(y2);
+      const float enn = ldedge(y + 2 < y1 ? y + 2 : y1 - 1);
+      float4 xn = zero4, rn = zero4;
       if constexpr (MODE == MODE_B)
       {
-        xv = zero4;
-        rv = zero4;
-        if (act)
-        {
-          xv = *reinterpret_cast<const float4 *>(a.x + idx);
-          rv = *reinterpret_cast<const float4 *>(a.r + idx);
-        }
+        const long long yn = y + 1 < y1 ? y + 1 : y1 - 1;
+        xn = load4<NT>(a.x + col0 + yn * n0);
+        rn = load4<false>(a.r + col0 + yn * n0);
       }
-      pn = zero4;
-      en = 0;
-      if (act && (y + 1 < g.n1 || (rowghost && g.has_hi)))
-        pn = src.ld4(idx + n0);
-      if (edge && y + 1 < y1)
-        en = src.ld1(idx + n0 + eoff);
 
+      // ---- row y ---------------------------------------------------------------------
       float lft = __shfl_up(pc.w, 1);
       float rgt = __shfl_down(pc.x, 1);
       if (lane == 0)
@@ -367,50 +468,47 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
       lv.y = 0.0f + axis_term(pc.z, pc.y, pc.x);
       lv.z = 0.0f + axis_term(pc.w, pc.z, pc.y);
       lv.w = 0.0f + axis_term(rgt, pc.w, pc.z);
-      if (g.d >= 2)
+      if (d >= 2)
       {
         lv.x += axis_term(pn.x, pc.x, pm.x);
         lv.y += axis_term(pn.y, pc.y, pm.y);
         lv.z += axis_term(pn.z, pc.z, pm.z);
         lv.w += axis_term(pn.w, pc.w, pm.w);
       }
-      for (int k = 2; k < g.d; k++)
+      for (int k = 2; k < d; k++)
       {
         const long long s = (long long)g.sk[k - 2];
-        float4 up = zero4, um = zero4;
-        if (act && ((okp >> (k - 2)) & 1u))
-          up = src.ld4(idx + s);
-        if (act && ((okm >> (k - 2)) & 1u))
-          um = src.ld4(idx - s);
+        const bool hp = (okp >> (k - 2)) & 1u, hm = (okm >> (k - 2)) & 1u;
+        const float4 up = sel4(hp, src.ld4(idx + (hp ? s : 0)));
+        const float4 um = sel4(hm, src.ld4(idx - (hm ? s : 0)));
         lv.x += axis_term(up.x, pc.x, um.x);
         lv.y += axis_term(up.y, pc.y, um.y);
         lv.z += axis_term(up.z, pc.z, um.z);
         lv.w += axis_term(up.w, pc.w, um.w);
         if constexpr (MODE == MODE_A && GHOST)
         {
-          if (k == g.d - 1 && act)
+          if (k == d - 1 && act)
           {
             if (st_lo)
-              *reinterpret_cast<float4 *>(p_new + idx - s) = um;
+              store4<NT>(p_new + idx - s, um);
             if (st_hi)
-              *reinterpret_cast<float4 *>(p_new + idx + s) = up;
+              store4<NT>(p_new + idx + s, up);
           }
         }
       }
-
-      // lanes past the end of the row hold zeros but see their neighbour's edge value
+      // lanes past the end of the row duplicate the last lane's data: no contribution
       if (!act)
         lv = zero4;
 
       if constexpr (MODE == MODE_STENCIL)
       {
         if (act)
-          *reinterpret_cast<float4 *>(a.out + idx) = lv;
+          store4<false>(a.out + idx, lv);
       }
       else if constexpr (MODE == MODE_A)
       {
         if (act)
-          *reinterpret_cast<float4 *>(p_new + idx) = pc;
+          store4<NT>(p_new + idx, pc);
         acc = fmaf(pc.x, lv.x, acc);
         acc = fmaf(pc.y, lv.y, acc);
         acc = fmaf(pc.z, lv.z, acc);
@@ -428,9 +526,11 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
         rv.w = fmaf(-alpha, lv.w, rv.w);
         if (act)
         {
-          *reinterpret_cast<float4 *>(a.x + idx) = xv;
-          *reinterpret_cast<float4 *>(a.r + idx) = rv;
+          store4<NT>(a.x + idx, xv);
+          store4<NT>(a.r + idx, rv);
         }
+        else
+          rv = zero4;
         acc = fmaf(rv.x, rv.x, acc);
         acc = fmaf(rv.y, rv.y, acc);
         acc = fmaf(rv.z, rv.z, acc);
@@ -438,13 +538,17 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
       }
       pm = pc;
       pc = pn;
+      pn = pnn;
       ec = en;
+      en = enn;
+      xv = xn;
+      rv = rn;
     }
     if constexpr (MODE == MODE_A)
     {
-      // after the loop idx addresses row y1 and pc holds it
-      if (rowghost && g.has_hi && y1 == g.n1 && act)
-        *reinterpret_cast<float4 *>(p_new + idx) = pc;
+      // pc now holds row y1
+      if (rowghost && g.has_hi && y1 == n1 && act)
+        store4<NT>(p_new + col0 + y1 * n0, pc);
     }
   }
   if constexpr (MODE != MODE_STENCIL)
@@ -457,7 +561,7 @@ template <int MODE, bool GHOST, int LAYOUT>
 __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArgs a)
 {
   __shared__ double sh[8];
-  Src<MODE> src;
+  Src<MODE, POL_PLAIN> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
   if constexpr (MODE == MODE_A)

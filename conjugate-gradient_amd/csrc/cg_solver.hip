@@ -107,6 +107,61 @@ static int max_blocks()
   return std::max(1, std::min(mb, 2 * CG_MAX_BLOCKS));
 }
 
+// Number of workgroups the chip keeps resident at once for the rows kernels: CUs times
+// workgroups per CU (256-thread workgroups at <= 72 VGPRs and ~90 SGPRs: 7 fit; 6 leaves a
+// margin).  A grid of exactly this size runs as one round with no partial second round.
+static int resident_blocks()
+{
+  static int cus = 0;
+  if (!cus)
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    else
+      cus = 256;
+    (void)hipGetLastError();
+  }
+  const int per_cu = std::max(1, env_int("CG_BLOCKS_PER_CU", 6));
+  return std::min(cus * per_cu, max_blocks());
+}
+
+// columns x segments decomposition of the rows engine (see cg_device.hpp)
+static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, RowsGeom &g, int &block, int &grid)
+{
+  memset(&g, 0, sizeof(g));
+  g.d = d;
+  g.n0 = n[0];
+  g.n1 = d >= 2 ? n[1] : 1;
+  const unsigned lanes = n[0] / 4;
+  block = (int)std::min(256u, (lanes + 63) / 64 * 64);
+  block = env_int("CG_ROWS_BLOCK", block);
+  g.nxc = (lanes + block - 1) / block;
+  unsigned long long ncols = g.nxc, stride = (unsigned long long)n[0] * g.n1;
+  for (int k = 2; k < d; k++)
+  {
+    g.nk[k - 2] = n[k];
+    g.sk[k - 2] = stride;
+    stride *= n[k];
+    ncols *= n[k];
+  }
+  // scale the resident-workgroup target by the workgroup size (it is counted in 256-thread units)
+  const unsigned long long target = (unsigned long long)resident_blocks() * (256 / block);
+  unsigned long long bpc = ncols >= target ? 1 : target / ncols;
+  bpc = std::min<unsigned long long>(bpc, std::max(1u, g.n1 / 4)); // at least ~4 rows per segment
+  bpc = std::max<unsigned long long>(bpc, 1);
+  bpc = (unsigned long long)env_int("CG_ROWS_BPC", (int)bpc);
+  bpc = std::max<unsigned long long>(1, std::min<unsigned long long>(bpc, g.n1));
+  const unsigned long long items = ncols * bpc;
+  CG_REQUIRE(items < (1ull << 32), "too many work items for the rows engine");
+  g.bpc = (unsigned)bpc;
+  g.nitems = (unsigned)items;
+  g.has_lo = has_lo;
+  g.has_hi = has_hi;
+  grid = (int)std::min<unsigned long long>(items, std::min<unsigned long long>(target, (unsigned long long)max_blocks()));
+}
+
 size_t Solver::plane_of(const SolverDesc &d)
 {
   size_t p = 1;
@@ -183,6 +238,7 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   CHECK(hipMemsetAsync(p0_base_, 0, buflen_ * sizeof(float), stream_));
   CHECK(hipMemsetAsync(p1_base_, 0, buflen_ * sizeof(float), stream_));
   build_geometry();
+  policy_ = env_int("CG_CACHE_POLICY", POL_KEEP_R);
   sumA_ = partA_;
   sumB_ = partB_;
   nA_ = nB_ = grid_;
@@ -246,44 +302,7 @@ void Solver::build_geometry()
 
   if (engine_ == ENGINE_ROWS)
   {
-    memset(&rg_, 0, sizeof(rg_));
-    rg_.d = d;
-    rg_.n0 = n[0];
-    rg_.n1 = d >= 2 ? n[1] : 1;
-    const unsigned lanes = n[0] / 4;
-    block_ = (int)std::min(256u, (lanes + 63) / 64 * 64);
-    block_ = env_int("CG_ROWS_BLOCK", block_);
-    rg_.nxc = (lanes + block_ - 1) / block_;
-    unsigned long long nhi = 1;
-    for (int k = 2; k < d; k++)
-    {
-      rg_.nk[k - 2] = n[k];
-      rg_.sk[k - 2] = sg_.stride[k];
-      nhi *= n[k];
-    }
-    unsigned ty = 0;
-    const unsigned cand[4] = {64, 32, 16, 8};
-    for (unsigned c : cand)
-    {
-      if (c > rg_.n1)
-        continue;
-      const unsigned long long tiles = (unsigned long long)rg_.nxc * ((rg_.n1 + c - 1) / c) * nhi;
-      if (tiles >= (unsigned long long)max_blocks())
-      {
-        ty = c;
-        break;
-      }
-    }
-    if (!ty)
-      ty = std::min(rg_.n1, 8u);
-    ty = (unsigned)env_int("CG_ROWS_TY", (int)ty);
-    ty = std::max(1u, std::min(ty, rg_.n1));
-    rg_.ty = ty;
-    rg_.nstrips = (rg_.n1 + ty - 1) / ty;
-    rg_.ntiles = (unsigned long long)rg_.nxc * rg_.nstrips * nhi;
-    rg_.has_lo = desc_.has_lo;
-    rg_.has_hi = desc_.has_hi;
-    grid_ = (int)std::min<unsigned long long>(rg_.ntiles, (unsigned long long)max_blocks());
+    make_rows_geom(d, n, desc_.has_lo, desc_.has_hi, rg_, block_, grid_);
   }
   else
   {
@@ -308,10 +327,25 @@ VecArgs Solver::args() const
   return a;
 }
 
-template <int MODE, bool GHOST>
-static void launch_rows(const RowsGeom &g, const VecArgs &a, int grid, int block, hipStream_t s)
+template <int MODE, bool GHOST, int POL>
+static void launch_rows_pol(const RowsGeom &g, const VecArgs &a, int grid, int block, hipStream_t s)
 {
-  hipLaunchKernelGGL((k_rows<MODE, GHOST>), dim3(grid), dim3(block), 0, s, g, a);
+  switch (g.d)
+  {
+  case 1: hipLaunchKernelGGL((k_rows<MODE, GHOST, 1, POL>), dim3(grid), dim3(block), 0, s, g, a); break;
+  case 2: hipLaunchKernelGGL((k_rows<MODE, GHOST, 2, POL>), dim3(grid), dim3(block), 0, s, g, a); break;
+  case 3: hipLaunchKernelGGL((k_rows<MODE, GHOST, 3, POL>), dim3(grid), dim3(block), 0, s, g, a); break;
+  default: hipLaunchKernelGGL((k_rows<MODE, GHOST, 0, POL>), dim3(grid), dim3(block), 0, s, g, a);
+  }
+}
+
+template <int MODE, bool GHOST>
+static void launch_rows(const RowsGeom &g, const VecArgs &a, int grid, int block, hipStream_t s, int pol = POL_PLAIN)
+{
+  if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
+    launch_rows_pol<MODE, GHOST, POL_KEEP_R>(g, a, grid, block, s);
+  else
+    launch_rows_pol<MODE, GHOST, POL_PLAIN>(g, a, grid, block, s);
 }
 
 template <int MODE, bool GHOST>
@@ -329,8 +363,8 @@ void Solver::launch_mode(int mode, bool ghost, const VecArgs &a)
   {
     switch (mode)
     {
-    case MODE_A: launch_rows<MODE_A, true>(rg_, a, grid_, block_, stream_); break;
-    case MODE_B: launch_rows<MODE_B, true>(rg_, a, grid_, block_, stream_); break;
+    case MODE_A: launch_rows<MODE_A, true>(rg_, a, grid_, block_, stream_, policy_); break;
+    case MODE_B: launch_rows<MODE_B, true>(rg_, a, grid_, block_, stream_, policy_); break;
     default:
       if (ghost)
         launch_rows<MODE_STENCIL, true>(rg_, a, grid_, block_, stream_);
@@ -579,32 +613,12 @@ void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode
   const bool aligned = (((uintptr_t)u | (uintptr_t)ddf) % 16) == 0;
   if (layout == LAYOUT_LEX && L % 4 == 0 && d <= CG_ROWS_MAXD + 2 && aligned)
   {
-    RowsGeom g{};
-    g.d = d;
-    g.n0 = L;
-    g.n1 = d >= 2 ? L : 1;
-    const unsigned lanes = L / 4;
-    const int block = (int)std::min(256u, (lanes + 63) / 64 * 64);
-    g.nxc = (lanes + block - 1) / block;
-    unsigned long long nhi = 1;
-    for (int k = 2; k < d; k++)
-    {
-      g.nk[k - 2] = L;
-      g.sk[k - 2] = sg.stride[k];
-      nhi *= L;
-    }
-    unsigned ty = std::min(g.n1, 8u);
-    const unsigned cand[4] = {64, 32, 16, 8};
-    for (unsigned c : cand)
-      if (c <= g.n1 && (unsigned long long)g.nxc * ((g.n1 + c - 1) / c) * nhi >= (unsigned long long)max_blocks())
-      {
-        ty = c;
-        break;
-      }
-    g.ty = ty;
-    g.nstrips = (g.n1 + ty - 1) / ty;
-    g.ntiles = (unsigned long long)g.nxc * g.nstrips * nhi;
-    const int grid = (int)std::min<unsigned long long>(g.ntiles, (unsigned long long)max_blocks());
+    RowsGeom g;
+    unsigned ext[CG_MAXD];
+    for (int k = 0; k < d; k++)
+      ext[k] = L;
+    int block = 256, grid = 1;
+    make_rows_geom(d, ext, 0, 0, g, block, grid);
     launch_rows<MODE_STENCIL, false>(g, a, grid, block, stream);
   }
   else

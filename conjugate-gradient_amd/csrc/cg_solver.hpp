@@ -95,6 +95,7 @@ private:
   CgState *st_ = nullptr;
   CgState *st_host_ = nullptr;
   int engine_ = ENGINE_SCALAR;
+  int policy_ = POL_KEEP_R;
   int layout_ = LAYOUT_LEX;
   RowsGeom rg_{};
   ScalarGeom sg_{};
