@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="2d-8192", help="2d-8192 | 3d-1024x128 | 3d-512 | 4d-128-morton | LxLx..[:mode]")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--force-slab", action="store_true", help="run the multi-rank driver even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -58,6 +59,25 @@ def workload_extents(name):
         ext = [int(v) for v in spec.split("x")]
         mode = int(m) if m else 0
     return ext, mode
+
+
+def measured_traffic(workload, kernel_mode):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 counter
+    passes (profiles/*_summary.json, written by tools/summarize_profile.py); None if no
+    profile of this workload is in the tree."""
+    import glob
+    tag = workload.replace("-", "")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_summary.json")))
+    if not files:
+        return None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+        for name, k in ks.items():
+            if f"k_rows<{kernel_mode}," in name or f"k_scalar<{kernel_mode}," in name:
+                return k.get("traffic_bytes")
+    except Exception:
+        return None
+    return None
 
 
 def cpu_baseline(ext, budget_s):
@@ -106,7 +126,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_slab:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     pkg = load_package()
@@ -123,12 +145,12 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
     roof = None
-    if world == 1:
+    if world == 1 and not args.force_slab:
         s = lib.make_solver(ext, index_mode=mode)
         s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
         s.iterate(args.warmup, use_graph=not args.no_graph)
@@ -148,7 +170,9 @@ def main():
         dom = ("B", msB, gB, BYTES_B) if msB >= msA else ("A", msA, gA, BYTES_A)
         roof = {"bound": "hbm", "kernel": f"k_rows<MODE_{dom[0]}>" if s.engine == 1 else f"k_scalar<MODE_{dom[0]}>",
                 "achieved": round(dom[2], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(dom[2] / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(dom[2] / HBM_PEAK_GBPS, 4),
+                "traffic": measured_traffic(args.workload, 2 if dom[0] == "B" else 1),
+                "algorithmic_bytes": dom[3] * N,
                 "algorithmic_bytes_per_point": dom[3], "ms_per_launch": round(dom[1], 5),
                 "other_kernel": {"ms_per_launch": round(msA if dom[0] == "B" else msB, 5),
                                  "achieved": round(gA if dom[0] == "B" else gB, 1)}}
@@ -196,7 +220,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ext, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,47 @@
+"""Worker for the multi-process slab tests: python slab_worker.py <out.npz> <L> <d> <iters>.
+Reads RANK / WORLD_SIZE / MASTER_* from the environment (gloo, CPU)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from conftest import load_package  # noqa: E402
+from fake_slab_ops import FakeSlabOps  # noqa: E402
+
+
+def main():
+    out, L, d, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    pkg = load_package()
+    from conjugate_gradient_amd.slab import SlabCG
+    assert L % world == 0
+    h = L // world
+    ext = [L] * (d - 1) + [h]
+    N = L ** d
+    rng = np.random.default_rng(123)
+    xt = rng.random(N).astype(np.float32)            # same on every rank
+    from oracle import oracle as orc
+    b = orc.Oracle().laplace_f32(xt, d, L)
+    n_loc = N // world
+    b_loc = torch.from_numpy(b[rank * n_loc:(rank + 1) * n_loc].copy())
+    x_loc = torch.zeros(n_loc, dtype=torch.float32)
+    s = SlabCG(None, ext, make_ops=lambda e, lo, hi: FakeSlabOps(e, lo, hi))
+    s.begin(b_loc, x_loc, 1e-6, 1)
+    s.iterate(iters)
+    n, res, hist = s.finish(hist_len=iters)
+    gathered = [torch.zeros(n_loc, dtype=torch.float32) for _ in range(world)]
+    dist.all_gather(gathered, x_loc)
+    if rank == 0:
+        np.savez(out, x=torch.cat(gathered).numpy(), xt=xt, b=b, iters=n, res=res, hist=np.array(hist))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""Slab code path of the HIP kernels on one GPU: several "virtual ranks" share the device,
+ghost planes are copied by hand and the dot products summed on the host.  This exercises
+exactly what each rank runs under torch.distributed (ghost-plane reads in both kernels, the
+local rebuild of p on ghost planes, all-reduced scalars through bind_sums)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def run_virtual(pkg, lib, L, d, nranks, b, iters, engine=0):
+    from conjugate_gradient_amd.slab import HipSlabOps
+    dev = torch.device("cuda", 0)
+    h = L // nranks
+    ext = [L] * (d - 1) + [h]
+    n_loc = (L ** d) // nranks
+    slabs, xs, bs = [], [], []
+    for r in range(nranks):
+        o = HipSlabOps(lib, ext, int(r > 0), int(r < nranks - 1), dev)
+        slabs.append(o)
+        bs.append(torch.from_numpy(b[r * n_loc:(r + 1) * n_loc].copy()).cuda())
+        xs.append(torch.zeros(n_loc, dtype=torch.float32, device=dev))
+
+    def sync():
+        torch.cuda.synchronize()
+
+    def allreduce(which):
+        for o in slabs:
+            o.reduce(which)
+        sync()
+        tot = sum(o.dots[which].item() for o in slabs)  # python floats: fixed rank order
+        for o in slabs:
+            o.dots[which] = tot
+        sync()
+
+    def exchange():
+        sync()
+        for r, o in enumerate(slabs):
+            g, n, pl = o.ghost_offset, n_loc, o.plane
+            if r > 0:
+                lo = slabs[r - 1]
+                o.r_buf[g - pl:g] = lo.r_buf[g + n - pl:g + n]
+            if r < nranks - 1:
+                hi = slabs[r + 1]
+                o.r_buf[g + n:g + n + pl] = hi.r_buf[g:g + pl]
+        sync()
+
+    for o, bb, xx in zip(slabs, bs, xs):
+        o.begin_local(bb, xx)
+    allreduce(1)
+    for o in slabs:
+        o.init_state(1e-6, 1, 0)
+    exchange()
+    for o in slabs:
+        o.add_iterations(iters)
+    for _ in range(iters):
+        for o in slabs:
+            o.kernel_A()
+        allreduce(0)
+        for o in slabs:
+            o.kernel_B()
+        allreduce(1)
+        exchange()
+    outs = [o.finish(hist_len=iters) for o in slabs]
+    sync()
+    x = torch.cat(xs).cpu().numpy()
+    assert len({o[0] for o in outs}) == 1, "ranks disagree on the iteration count"
+    return x, outs[0][0], outs[0][2]
+
+
+@pytest.mark.parametrize("L,d,nranks", [(16, 2, 2), (64, 2, 4), (16, 3, 2), (16, 3, 4), (10, 2, 2), (6, 3, 3), (8, 4, 2)])
+def test_virtual_ranks_match_single_gpu_and_oracle(pkg, lib, oracle, L, d, nranks):
+    N = L ** d
+    rng = np.random.default_rng(L + d)
+    xt = rng.random(N).astype(np.float32)
+    b = oracle.laplace_f32(xt, d, L)
+    x, iters, hist = run_virtual(pkg, lib, L, d, nranks, b, 200)
+    xe, rese, iterse, histe = oracle.cg_f32(b, L, d, hist_len=200)
+    assert abs(iters - iterse) <= max(2, 0.05 * iterse), (iters, iterse)
+    assert np.all(np.abs(x - xt) < 1e-3)
+    assert np.linalg.norm(x - xe) <= 1e-4 * np.linalg.norm(xe)
+    # single solver on the whole grid
+    x1 = torch.zeros(N, dtype=torch.float32, device="cuda")
+    bd = torch.from_numpy(b).cuda()
+    _, it1, h1 = lib.conjugate_gradient_gpu_ex(bd.data_ptr(), x1.data_ptr(), L, d, hist_len=200)
+    assert abs(iters - it1) <= max(2, 0.05 * it1)
+    assert np.linalg.norm(x - x1.cpu().numpy()) <= 1e-5 * np.linalg.norm(xe)
+    n = min(len(hist), len(h1), 8)
+    assert np.allclose(hist[:n], h1[:n], rtol=1e-5)
