@@ -1,0 +1,276 @@
+// cg_planes.hpp -- the 3-D engine: workgroups march along the slowest axis.
+//
+// In 3-D the rows engine fetches the z-1 and z+1 neighbours of every point straight from
+// memory, which triples the L2-side traffic of the stencil input (measured at 1024x1024x128:
+// 5.8 and 6.4 words per point leave L2 in kernels A and B where 3 and 5 are needed).  Here
+// each element of the stencil input is loaded once per work item:
+//
+//   * a work item is a tile of 256 points of axis 0 by TY = waves*R rows of axis 1, marched
+//     along a segment of axis 2;
+//   * a lane owns 4 consecutive points of axis 0 in R consecutive rows; planes z-1, z, z+1 of
+//     its rows stay in registers (the z neighbours), rows y-1 / y+1 inside the R rows are the
+//     lane's own registers, and the two rows just outside a wave's R rows come from the
+//     neighbouring wave through LDS (one 16-byte write and read per lane, row and plane) or,
+//     at the tile's edge, from memory;
+//   * x neighbours are lane shifts, the two elements outside the wave's span a 2-lane load.
+//
+// One workgroup barrier per plane orders the LDS hand-off (double-buffered by plane parity).
+// The modes, the cache policy and the iteration control are those of the rows engine.
+#pragma once
+#include "cg_device.hpp"
+
+namespace cgamd
+{
+
+struct PlanesGeom
+{
+  unsigned n0, n1, n2;
+  unsigned nxc, nyt, nzs; // tiles along axis 0 (256 points), axis 1 (TY rows), segments of axis 2
+  unsigned nitems;
+  int has_lo, has_hi;
+};
+
+constexpr int CG_PLANES_MAX_WAVES = 8;
+
+template <int MODE, bool GHOST, int POL, int R>
+__global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArgs a)
+{
+  __shared__ double sh[8];
+  // [plane parity][wave][0 = first row, 1 = last row][lane]
+  __shared__ float4 halo[2][CG_PLANES_MAX_WAVES][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  constexpr bool NT = POL == POL_KEEP_R;
+  Src<MODE, POL> src;
+  float *__restrict__ p_new = nullptr;
+  float coef = 0;
+  if constexpr (MODE == MODE_A)
+  {
+    const IterCtl c = prologue_A(a, sh);
+    if (!c.active)
+      return;
+    src.p = (c.k & 1) ? a.p1 : a.p0;
+    p_new = (c.k & 1) ? a.p0 : a.p1;
+    src.r = a.r;
+    src.beta = c.coef;
+  }
+  else if constexpr (MODE == MODE_B)
+  {
+    const IterCtl c = prologue_B(a, sh);
+    if (!c.active)
+      return;
+    src.p = (c.k & 1) ? a.p0 : a.p1;
+    coef = c.coef;
+  }
+  else
+  {
+    src.p = a.u;
+  }
+  const float alpha = coef;
+  float acc = 0;
+  const float4 zero4 = make_float4(0, 0, 0, 0);
+  const long long n0 = g.n0, n1 = g.n1, n2 = g.n2;
+  const long long sy = n0, sz = n0 * n1;
+  const unsigned TY = (unsigned)nw * R;
+
+  for (unsigned item = blockIdx.x; item < g.nitems; item += gridDim.x)
+  {
+    const unsigned zs = item % g.nzs;
+    unsigned t = item / g.nzs;
+    const unsigned xc = t % g.nxc;
+    const unsigned yt = t / g.nxc;
+    const long long z0 = (long long)((unsigned long long)zs * g.n2 / g.nzs);
+    const long long z1 = (long long)((unsigned long long)(zs + 1) * g.n2 / g.nzs);
+    if (z0 >= z1)
+      continue;
+    const unsigned x0 = xc * 256u + (unsigned)lane * 4u;
+    const bool act = x0 < g.n0;
+    const long long xcl = act ? x0 : g.n0 - 4u;
+    const long long yb = (long long)yt * TY + (long long)w * R; // this wave's first row
+    const bool el = act && lane == 0 && x0 > 0;
+    const bool er = act && lane == 63 && x0 + 4 < g.n0;
+    const bool edge = el || er;
+    const long long eoff = (lane == 0) ? -1 : 4;
+    const bool rightmost = (lane == 63) || (x0 + 4 >= g.n0);
+
+    auto zvalid = [&](long long z) { return GHOST || (z >= 0 && z < n2); };
+    auto zaddr = [&](long long z) { return GHOST ? z : (z < 0 ? 0 : (z >= n2 ? n2 - 1 : z)); };
+    // one row of the stencil input (zero outside the grid; ghost planes are real memory)
+    auto ldrow = [&](long long y, long long z) -> float4 {
+      const bool ok = y >= 0 && y < n1 && zvalid(z);
+      const long long yc = y < 0 ? 0 : (y >= n1 ? n1 - 1 : y);
+      const float4 v = src.ld4(zaddr(z) * sz + yc * sy + xcl);
+      return sel4(ok, v);
+    };
+    auto ldplane = [&](long long z, float4(&out)[R]) {
+#pragma unroll
+      for (int j = 0; j < R; j++)
+        out[j] = ldrow(yb + j, z);
+    };
+    auto ldedges = [&](long long z, float(&e)[R]) {
+#pragma unroll
+      for (int j = 0; j < R; j++)
+      {
+        e[j] = 0.0f;
+        if (edge && yb + j < n1)
+          e[j] = src.ld1(z * sz + (yb + j) * sy + xcl + eoff);
+      }
+    };
+
+    float4 pm[R], pc[R], pn[R];
+    float ec[R], en[R];
+    float4 hu_ext = zero4, hd_ext = zero4; // rows outside the tile, for the first / last wave
+    ldplane(z0 - 1, pm);
+    ldplane(z0, pc);
+    ldedges(z0, ec);
+    if (w == 0)
+      hu_ext = ldrow(yb - 1, z0);
+    if (w == nw - 1)
+      hd_ext = ldrow(yb + R, z0);
+    halo[z0 & 1][w][0][lane] = pc[0];
+    halo[z0 & 1][w][1][lane] = pc[R - 1];
+    if constexpr (MODE == MODE_A && GHOST)
+    {
+      if (g.has_lo && z0 == 0 && act)
+      {
+#pragma unroll
+        for (int j = 0; j < R; j++)
+          if (yb + j < n1)
+            store4<NT>(p_new + (-1) * sz + (yb + j) * sy + xcl, pm[j]);
+      }
+    }
+    __syncthreads();
+
+    for (long long z = z0; z < z1; z++)
+    {
+      const bool more = z + 1 < z1;
+      // ---- loads for the next plane and this plane's x, r ---------------------------------
+      ldplane(z + 1, pn);
+      float4 hu_n = zero4, hd_n = zero4;
+#pragma unroll
+      for (int j = 0; j < R; j++)
+        en[j] = 0.0f;
+      if (more)
+      {
+        ldedges(z + 1, en);
+        if (w == 0)
+          hu_n = ldrow(yb - 1, z + 1);
+        if (w == nw - 1)
+          hd_n = ldrow(yb + R, z + 1);
+      }
+      float4 xv[R], rv[R];
+      if constexpr (MODE == MODE_B)
+      {
+#pragma unroll
+        for (int j = 0; j < R; j++)
+        {
+          const long long yc = yb + j < n1 ? yb + j : n1 - 1;
+          xv[j] = load4<NT>(a.x + z * sz + yc * sy + xcl);
+          rv[j] = load4<false>(a.r + z * sz + yc * sy + xcl);
+        }
+      }
+      // ---- rows just outside this wave's rows, plane z ------------------------------------
+      const float4 hu = (w == 0) ? hu_ext : halo[z & 1][w - 1][1][lane];
+      const float4 hd = (w == nw - 1) ? hd_ext : halo[z & 1][w + 1][0][lane];
+
+#pragma unroll
+      for (int j = 0; j < R; j++)
+      {
+        const bool rowok = act && (yb + j < n1);
+        const long long idx = z * sz + (yb + j) * sy + xcl;
+        const float4 c = pc[j];
+        const float4 yu = (j + 1 < R) ? pc[(j + 1 < R) ? j + 1 : j] : hd; // y + 1
+        const float4 yd = (j > 0) ? pc[(j > 0) ? j - 1 : j] : hu;         // y - 1
+        float lft = __shfl_up(c.w, 1);
+        float rgt = __shfl_down(c.x, 1);
+        if (lane == 0)
+          lft = ec[j];
+        if (rightmost)
+          rgt = (lane == 63) ? ec[j] : 0.0f;
+        float4 lv;
+        lv.x = 0.0f + axis_term(c.y, c.x, lft);
+        lv.y = 0.0f + axis_term(c.z, c.y, c.x);
+        lv.z = 0.0f + axis_term(c.w, c.z, c.y);
+        lv.w = 0.0f + axis_term(rgt, c.w, c.z);
+        lv.x += axis_term(yu.x, c.x, yd.x);
+        lv.y += axis_term(yu.y, c.y, yd.y);
+        lv.z += axis_term(yu.z, c.z, yd.z);
+        lv.w += axis_term(yu.w, c.w, yd.w);
+        lv.x += axis_term(pn[j].x, c.x, pm[j].x);
+        lv.y += axis_term(pn[j].y, c.y, pm[j].y);
+        lv.z += axis_term(pn[j].z, c.z, pm[j].z);
+        lv.w += axis_term(pn[j].w, c.w, pm[j].w);
+        if (!rowok)
+          lv = zero4;
+
+        if constexpr (MODE == MODE_STENCIL)
+        {
+          if (rowok)
+            store4<false>(a.out + idx, lv);
+        }
+        else if constexpr (MODE == MODE_A)
+        {
+          if (rowok)
+            store4<NT>(p_new + idx, c);
+          acc = fmaf(c.x, lv.x, acc);
+          acc = fmaf(c.y, lv.y, acc);
+          acc = fmaf(c.z, lv.z, acc);
+          acc = fmaf(c.w, lv.w, acc);
+        }
+        else
+        {
+          float4 xo = xv[j], ro = rv[j];
+          xo.x = fmaf(alpha, c.x, xo.x);
+          xo.y = fmaf(alpha, c.y, xo.y);
+          xo.z = fmaf(alpha, c.z, xo.z);
+          xo.w = fmaf(alpha, c.w, xo.w);
+          ro.x = fmaf(-alpha, lv.x, ro.x);
+          ro.y = fmaf(-alpha, lv.y, ro.y);
+          ro.z = fmaf(-alpha, lv.z, ro.z);
+          ro.w = fmaf(-alpha, lv.w, ro.w);
+          if (rowok)
+          {
+            store4<NT>(a.x + idx, xo);
+            store4<NT>(a.r + idx, ro);
+          }
+          else
+            ro = zero4;
+          acc = fmaf(ro.x, ro.x, acc);
+          acc = fmaf(ro.y, ro.y, acc);
+          acc = fmaf(ro.z, ro.z, acc);
+          acc = fmaf(ro.w, ro.w, acc);
+        }
+      }
+      // ---- hand this wave's boundary rows of plane z+1 to its neighbours -------------------
+      if (more)
+      {
+        halo[(z + 1) & 1][w][0][lane] = pn[0];
+        halo[(z + 1) & 1][w][1][lane] = pn[R - 1];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < R; j++)
+      {
+        pm[j] = pc[j];
+        pc[j] = pn[j];
+        ec[j] = en[j];
+      }
+      hu_ext = hu_n;
+      hd_ext = hd_n;
+    }
+    if constexpr (MODE == MODE_A && GHOST)
+    {
+      // pc now holds plane z1
+      if (g.has_hi && z1 == n2 && act)
+      {
+#pragma unroll
+        for (int j = 0; j < R; j++)
+          if (yb + j < n1)
+            store4<NT>(p_new + z1 * sz + (yb + j) * sy + xcl, pc[j]);
+      }
+    }
+  }
+  if constexpr (MODE != MODE_STENCIL)
+    block_write_partial(acc, a.part_out, sh);
+}
+
+} // namespace cgamd

@@ -162,6 +162,42 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
   grid = (int)std::min<unsigned long long>(items, std::min<unsigned long long>(target, (unsigned long long)max_blocks()));
 }
 
+// tiles x segments decomposition of the planes engine (see cg_planes.hpp)
+static void make_planes_geom(const unsigned *n, int has_lo, int has_hi, PlanesGeom &g, int &block, int &grid, int &R)
+{
+  memset(&g, 0, sizeof(g));
+  g.n0 = n[0];
+  g.n1 = n[1];
+  g.n2 = n[2];
+  R = env_int("CG_PLANES_R", 2) >= 4 ? 4 : 2;
+  int nw = env_int("CG_PLANES_WAVES", 8);
+  nw = std::max(1, std::min(nw, CG_PLANES_MAX_WAVES));
+  nw = (int)std::min<unsigned>((unsigned)nw, (n[1] + R - 1) / R);
+  block = nw * 64;
+  const unsigned ty = (unsigned)nw * R;
+  g.nxc = (n[0] + 255) / 256;
+  g.nyt = (n[1] + ty - 1) / ty;
+  const unsigned long long ncols = (unsigned long long)g.nxc * g.nyt;
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    cus = prop.multiProcessorCount;
+  (void)hipGetLastError();
+  const unsigned long long target =
+      std::min<unsigned long long>((unsigned long long)cus * std::max(1, env_int("CG_PLANES_BPCU", 2)), max_blocks());
+  unsigned long long nzs = ncols >= target ? 1 : target / ncols;
+  nzs = std::min<unsigned long long>(nzs, std::max(1u, n[2] / 8)); // keep segments >= 8 planes
+  nzs = (unsigned long long)env_int("CG_PLANES_NZS", (int)nzs);
+  nzs = std::max<unsigned long long>(1, std::min<unsigned long long>(nzs, n[2]));
+  g.nzs = (unsigned)nzs;
+  const unsigned long long items = ncols * nzs;
+  CG_REQUIRE(items < (1ull << 32), "too many work items for the planes engine");
+  g.nitems = (unsigned)items;
+  g.has_lo = has_lo;
+  g.has_hi = has_hi;
+  grid = (int)std::min<unsigned long long>(items, target);
+}
+
 size_t Solver::plane_of(const SolverDesc &d)
 {
   size_t p = 1;
@@ -238,7 +274,11 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   CHECK(hipMemsetAsync(p0_base_, 0, buflen_ * sizeof(float), stream_));
   CHECK(hipMemsetAsync(p1_base_, 0, buflen_ * sizeof(float), stream_));
   build_geometry();
-  policy_ = env_int("CG_CACHE_POLICY", POL_KEEP_R);
+  // r can only stay in the 256 MiB Infinity Cache if it fits; the rows engine in d >= 3 also
+  // re-reads p's far neighbours, which non-temporal loads would push back to HBM
+  // (the planes engine loads p once, so streaming hints pay there at any size)
+  const bool keep_r = engine_ == ENGINE_PLANES || (N_ * sizeof(float) <= (256ull << 20) && desc_.d <= 2);
+  policy_ = env_int("CG_CACHE_POLICY", keep_r ? POL_KEEP_R : POL_PLAIN);
   sumA_ = partA_;
   sumB_ = partB_;
   nA_ = nB_ = grid_;
@@ -296,13 +336,21 @@ void Solver::build_geometry()
   }
 
   const bool rows_ok = layout_ == LAYOUT_LEX && (n[0] % 4 == 0) && d <= CG_ROWS_MAXD + 2;
-  engine_ = desc_.engine == ENGINE_AUTO ? (rows_ok ? ENGINE_ROWS : ENGINE_SCALAR) : desc_.engine;
+  const bool planes_ok = rows_ok && d == 3;
+  engine_ = desc_.engine == ENGINE_AUTO ? (planes_ok ? ENGINE_PLANES : (rows_ok ? ENGINE_ROWS : ENGINE_SCALAR))
+                                        : desc_.engine;
   if (engine_ == ENGINE_ROWS)
     CG_REQUIRE(rows_ok, "the rows engine needs the lexicographic layout, n0 % 4 == 0 and d <= 10");
+  if (engine_ == ENGINE_PLANES)
+    CG_REQUIRE(planes_ok, "the planes engine needs a 3-D lexicographic grid with n0 % 4 == 0");
 
   if (engine_ == ENGINE_ROWS)
   {
     make_rows_geom(d, n, desc_.has_lo, desc_.has_hi, rg_, block_, grid_);
+  }
+  else if (engine_ == ENGINE_PLANES)
+  {
+    make_planes_geom(n, desc_.has_lo, desc_.has_hi, pg_, block_, grid_, planes_r_);
   }
   else
   {
@@ -348,6 +396,25 @@ static void launch_rows(const RowsGeom &g, const VecArgs &a, int grid, int block
     launch_rows_pol<MODE, GHOST, POL_PLAIN>(g, a, grid, block, s);
 }
 
+template <int MODE, bool GHOST, int POL>
+static void launch_planes_pol(const PlanesGeom &g, const VecArgs &a, int grid, int block, int R, hipStream_t s)
+{
+  if (R >= 4)
+    hipLaunchKernelGGL((k_planes<MODE, GHOST, POL, 4>), dim3(grid), dim3(block), 0, s, g, a);
+  else
+    hipLaunchKernelGGL((k_planes<MODE, GHOST, POL, 2>), dim3(grid), dim3(block), 0, s, g, a);
+}
+
+template <int MODE, bool GHOST>
+static void launch_planes(const PlanesGeom &g, const VecArgs &a, int grid, int block, int R, hipStream_t s,
+                          int pol = POL_PLAIN)
+{
+  if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
+    launch_planes_pol<MODE, GHOST, POL_KEEP_R>(g, a, grid, block, R, s);
+  else
+    launch_planes_pol<MODE, GHOST, POL_PLAIN>(g, a, grid, block, R, s);
+}
+
 template <int MODE, bool GHOST>
 static void launch_scalar(const ScalarGeom &g, const VecArgs &a, int layout, int grid, int block, hipStream_t s)
 {
@@ -359,7 +426,20 @@ static void launch_scalar(const ScalarGeom &g, const VecArgs &a, int layout, int
 
 void Solver::launch_mode(int mode, bool ghost, const VecArgs &a)
 {
-  if (engine_ == ENGINE_ROWS)
+  if (engine_ == ENGINE_PLANES)
+  {
+    switch (mode)
+    {
+    case MODE_A: launch_planes<MODE_A, true>(pg_, a, grid_, block_, planes_r_, stream_, policy_); break;
+    case MODE_B: launch_planes<MODE_B, true>(pg_, a, grid_, block_, planes_r_, stream_, policy_); break;
+    default:
+      if (ghost)
+        launch_planes<MODE_STENCIL, true>(pg_, a, grid_, block_, planes_r_, stream_);
+      else
+        launch_planes<MODE_STENCIL, false>(pg_, a, grid_, block_, planes_r_, stream_);
+    }
+  }
+  else if (engine_ == ENGINE_ROWS)
   {
     switch (mode)
     {
@@ -611,7 +691,15 @@ void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode
   a.u = u;
   a.out = ddf;
   const bool aligned = (((uintptr_t)u | (uintptr_t)ddf) % 16) == 0;
-  if (layout == LAYOUT_LEX && L % 4 == 0 && d <= CG_ROWS_MAXD + 2 && aligned)
+  if (layout == LAYOUT_LEX && L % 4 == 0 && d == 3 && aligned && env_int("CG_STENCIL_PLANES", 1))
+  {
+    PlanesGeom g;
+    unsigned ext[3] = {L, L, L};
+    int block = 256, grid = 1, R = 4;
+    make_planes_geom(ext, 0, 0, g, block, grid, R);
+    launch_planes<MODE_STENCIL, false>(g, a, grid, block, R, stream);
+  }
+  else if (layout == LAYOUT_LEX && L % 4 == 0 && d <= CG_ROWS_MAXD + 2 && aligned)
   {
     RowsGeom g;
     unsigned ext[CG_MAXD];

@@ -7,6 +7,7 @@
 #include <stddef.h>
 
 #include "cg_device.hpp"
+#include "cg_planes.hpp"
 
 namespace cgamd
 {
@@ -15,7 +16,8 @@ enum Engine
 {
   ENGINE_AUTO = 0,
   ENGINE_ROWS = 1,
-  ENGINE_SCALAR = 2
+  ENGINE_SCALAR = 2,
+  ENGINE_PLANES = 3 // 3-D only: march along axis 2
 };
 
 struct SolverDesc
@@ -98,6 +100,8 @@ private:
   int policy_ = POL_KEEP_R;
   int layout_ = LAYOUT_LEX;
   RowsGeom rg_{};
+  PlanesGeom pg_{};
+  int planes_r_ = 4;
   ScalarGeom sg_{};
   int grid_ = 1, block_ = 256;
   hipGraphExec_t graph_ = nullptr;
