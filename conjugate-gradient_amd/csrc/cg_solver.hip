@@ -108,8 +108,7 @@ static int max_blocks()
 }
 
 // Number of workgroups the chip keeps resident at once for the rows kernels: CUs times
-// workgroups per CU (256-thread workgroups at <= 72 VGPRs and ~90 SGPRs: 7 fit; 6 leaves a
-// margin).  A grid of exactly this size runs as one round with no partial second round.
+// workgroups per CU (kernel B needs 82 VGPRs: 5 workgroups of 256 fit; 4 measured fastest).  A grid of exactly this size runs as one round with no partial second round.
 static int resident_blocks()
 {
   static int cus = 0;
@@ -123,7 +122,7 @@ static int resident_blocks()
       cus = 256;
     (void)hipGetLastError();
   }
-  const int per_cu = std::max(1, env_int("CG_BLOCKS_PER_CU", 6));
+  const int per_cu = std::max(1, env_int("CG_BLOCKS_PER_CU", 4));
   return std::min(cus * per_cu, max_blocks());
 }
 
@@ -196,6 +195,23 @@ static void make_planes_geom(const unsigned *n, int has_lo, int has_hi, PlanesGe
   g.has_lo = has_lo;
   g.has_hi = has_hi;
   grid = (int)std::min<unsigned long long>(items, target);
+}
+
+// contiguous Z-curve ranges, one per workgroup
+static void make_morton_geom(int d, unsigned long long N, MortonGeom &g, int &block, int &grid)
+{
+  memset(&g, 0, sizeof(g));
+  g.d = d;
+  g.N = N;
+  for (int k = 0; k < d; k++)
+    g.mmask[k] = morton_mask(d, k);
+  block = 256;
+  const unsigned long long quads = N / 4;
+  const unsigned long long want = (quads + block - 1) / block;
+  grid = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(want, (unsigned long long)std::min(env_int("CG_MORTON_BLOCKS", 2 * CG_MAX_BLOCKS), 2 * CG_MAX_BLOCKS)));
+  // with at least one LDS tile per workgroup the tiled kernel is used: never more workgroups than tiles
+  if (N % CG_MORTON_TILE == 0 && N / CG_MORTON_TILE >= 64)
+    grid = (int)std::min<unsigned long long>((unsigned long long)grid, N / CG_MORTON_TILE);
 }
 
 size_t Solver::plane_of(const SolverDesc &d)
@@ -277,7 +293,7 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   // r can only stay in the 256 MiB Infinity Cache if it fits; the rows engine in d >= 3 also
   // re-reads p's far neighbours, which non-temporal loads would push back to HBM
   // (the planes engine loads p once, so streaming hints pay there at any size)
-  const bool keep_r = engine_ == ENGINE_PLANES || (N_ * sizeof(float) <= (256ull << 20) && desc_.d <= 2);
+  const bool keep_r = engine_ == ENGINE_PLANES || engine_ == ENGINE_MORTON4 || (N_ * sizeof(float) <= (256ull << 20) && desc_.d <= 2);
   policy_ = env_int("CG_CACHE_POLICY", keep_r ? POL_KEEP_R : POL_PLAIN);
   sumA_ = partA_;
   sumB_ = partB_;
@@ -337,8 +353,12 @@ void Solver::build_geometry()
 
   const bool rows_ok = layout_ == LAYOUT_LEX && (n[0] % 4 == 0) && d <= CG_ROWS_MAXD + 2;
   const bool planes_ok = rows_ok && d == 3;
-  engine_ = desc_.engine == ENGINE_AUTO ? (planes_ok ? ENGINE_PLANES : (rows_ok ? ENGINE_ROWS : ENGINE_SCALAR))
-                                        : desc_.engine;
+  const bool morton4_ok = layout_ == LAYOUT_MORTON && d >= 2;
+  engine_ = desc_.engine == ENGINE_AUTO
+                ? (planes_ok ? ENGINE_PLANES : (rows_ok ? ENGINE_ROWS : (morton4_ok ? ENGINE_MORTON4 : ENGINE_SCALAR)))
+                : desc_.engine;
+  if (engine_ == ENGINE_MORTON4)
+    CG_REQUIRE(morton4_ok, "the 4-per-lane Morton engine needs the Morton layout and d >= 2");
   if (engine_ == ENGINE_ROWS)
     CG_REQUIRE(rows_ok, "the rows engine needs the lexicographic layout, n0 % 4 == 0 and d <= 10");
   if (engine_ == ENGINE_PLANES)
@@ -351,6 +371,10 @@ void Solver::build_geometry()
   else if (engine_ == ENGINE_PLANES)
   {
     make_planes_geom(n, desc_.has_lo, desc_.has_hi, pg_, block_, grid_, planes_r_);
+  }
+  else if (engine_ == ENGINE_MORTON4)
+  {
+    make_morton_geom(d, N_, mg_, block_, grid_);
   }
   else
   {
@@ -415,6 +439,25 @@ static void launch_planes(const PlanesGeom &g, const VecArgs &a, int grid, int b
     launch_planes_pol<MODE, GHOST, POL_PLAIN>(g, a, grid, block, R, s);
 }
 
+template <int MODE>
+static void launch_morton4(const MortonGeom &g, const VecArgs &a, int grid, int block, hipStream_t s, int pol = POL_PLAIN)
+{
+  // grids of at least one tile per workgroup use the LDS-tiled kernel
+  const bool tiled = g.N >= (unsigned long long)CG_MORTON_TILE * grid && g.N % CG_MORTON_TILE == 0 &&
+                     env_int("CG_MORTON_TILED", 1);
+  if (tiled)
+  {
+    if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
+      hipLaunchKernelGGL((k_morton_tile<MODE, POL_KEEP_R>), dim3(grid), dim3(block), 0, s, g, a);
+    else
+      hipLaunchKernelGGL((k_morton_tile<MODE, POL_PLAIN>), dim3(grid), dim3(block), 0, s, g, a);
+  }
+  else if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
+    hipLaunchKernelGGL((k_morton4<MODE, POL_KEEP_R>), dim3(grid), dim3(block), 0, s, g, a);
+  else
+    hipLaunchKernelGGL((k_morton4<MODE, POL_PLAIN>), dim3(grid), dim3(block), 0, s, g, a);
+}
+
 template <int MODE, bool GHOST>
 static void launch_scalar(const ScalarGeom &g, const VecArgs &a, int layout, int grid, int block, hipStream_t s)
 {
@@ -426,7 +469,16 @@ static void launch_scalar(const ScalarGeom &g, const VecArgs &a, int layout, int
 
 void Solver::launch_mode(int mode, bool ghost, const VecArgs &a)
 {
-  if (engine_ == ENGINE_PLANES)
+  if (engine_ == ENGINE_MORTON4)
+  {
+    switch (mode)
+    {
+    case MODE_A: launch_morton4<MODE_A>(mg_, a, grid_, block_, stream_, policy_); break;
+    case MODE_B: launch_morton4<MODE_B>(mg_, a, grid_, block_, stream_, policy_); break;
+    default: launch_morton4<MODE_STENCIL>(mg_, a, grid_, block_, stream_);
+    }
+  }
+  else if (engine_ == ENGINE_PLANES)
   {
     switch (mode)
     {
@@ -716,7 +768,16 @@ void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode
       int bits = 0;
       for (unsigned v = L; v > 1; v >>= 1)
         bits++;
-      CG_REQUIRE(is_pow2(L) && bits * d <= 32, "the Morton layout needs L = 2^m with m*d <= 32");
+      CG_REQUIRE(is_pow2(L) && bits * d <= 32 && sg.N < (1ull << 32), "the Morton layout needs L = 2^m with m*d < 32");
+      if (d >= 2 && aligned)
+      {
+        MortonGeom g;
+        int block = 256, grid = 1;
+        make_morton_geom(d, sg.N, g, block, grid);
+        launch_morton4<MODE_STENCIL>(g, a, grid, block, stream);
+        CHECK(hipGetLastError());
+        return;
+      }
     }
     const unsigned long long nb = (sg.N + 255) / 256;
     const int grid = (int)std::min<unsigned long long>(nb, (unsigned long long)max_blocks());

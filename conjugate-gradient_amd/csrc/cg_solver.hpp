@@ -7,6 +7,7 @@
 #include <stddef.h>
 
 #include "cg_device.hpp"
+#include "cg_morton.hpp"
 #include "cg_planes.hpp"
 
 namespace cgamd
@@ -17,7 +18,8 @@ enum Engine
   ENGINE_AUTO = 0,
   ENGINE_ROWS = 1,
   ENGINE_SCALAR = 2,
-  ENGINE_PLANES = 3 // 3-D only: march along axis 2
+  ENGINE_PLANES = 3, // 3-D only: march along axis 2
+  ENGINE_MORTON4 = 4 // Morton layout, 4 points per lane
 };
 
 struct SolverDesc
@@ -101,6 +103,7 @@ private:
   int layout_ = LAYOUT_LEX;
   RowsGeom rg_{};
   PlanesGeom pg_{};
+  MortonGeom mg_{};
   int planes_r_ = 4;
   ScalarGeom sg_{};
   int grid_ = 1, block_ = 256;

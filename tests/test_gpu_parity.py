@@ -105,7 +105,7 @@ def test_stencil_partial_launch_keeps_reference_meaning(lib, oracle, L, d):
     assert np.array_equal(got[:24], want[:24]) and np.all(got[24:] == -7.0)
 
 
-@pytest.mark.parametrize("L,d", [(4, 2), (16, 2), (8, 3), (16, 3), (8, 4), (16, 4)])
+@pytest.mark.parametrize("L,d", [(2, 2), (4, 2), (16, 2), (8, 3), (16, 3), (8, 4), (16, 4), (4, 5), (2, 7), (16, 1)])
 def test_stencil_morton_bit_exact(lib, oracle, L, d):
     N = L ** d
     u = np.random.default_rng(11).standard_normal(N).astype(np.float32)
