@@ -22,8 +22,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(src, pattern))
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+    return g[-1] if g else None   # the newest run if several were merged into the folder
 
 
 shutil.copy(one("stats/*/*kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
