@@ -362,3 +362,71 @@ def test_recurrence_residual_equals_true_residual_large(lib, L, d):
     true_res = (b.double() - Ax.double()).norm().item()
     assert abs(true_res - rec) <= 1e-3 * rec, (true_res, rec)
     s.close()
+
+
+def morton_perm(L, d):
+    """perm[lex] = Z-curve index, vectorised (interleave.cuh:110-118: coordinate k owns bits k, k+d, ...)."""
+    N = L ** d
+    lex = np.arange(N, dtype=np.int64)
+    bits = L.bit_length() - 1
+    out = np.zeros(N, dtype=np.int64)
+    rem = lex.copy()
+    for k in range(d):
+        c = rem % L
+        rem //= L
+        for b in range(bits):
+            out |= ((c >> b) & 1) << (b * d + k)
+    return out
+
+
+@pytest.mark.parametrize("L,d", [(32, 4), (128, 3), (1024, 2)])
+def test_morton_tiled_engine_equals_lexicographic_large(lib, oracle, L, d):
+    """The LDS-tiled Z-curve kernels against the lexicographic engines on the same data, at
+    sizes with hundreds of tiles: stencil bit-exact, 30 CG iterations to rounding."""
+    N = L ** d
+    perm = morton_perm(L, d)
+    if L <= 32:
+        assert np.array_equal(perm[:4096], oracle.lex_to_morton_perm(L, d)[:4096])
+    rng = np.random.default_rng(17)
+    u = rng.random(N).astype(np.float32)
+    um = np.zeros(N, np.float32)
+    um[perm] = u
+    ud, umd = dev(u), dev(um)
+    a_lex = torch.empty(N, dtype=torch.float32, device="cuda")
+    a_mor = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.laplace_gpu_jl(a_lex.data_ptr(), ud.data_ptr(), 0.0, d, L, N, 0, (N + 255) // 256, 256)
+    lib.laplace_gpu_jl(a_mor.data_ptr(), umd.data_ptr(), 0.0, d, L, N, 2, (N + 255) // 256, 256)
+    assert np.array_equal(a_mor.cpu().numpy()[perm], a_lex.cpu().numpy())
+    xl = torch.zeros(N, dtype=torch.float32, device="cuda")
+    xm = torch.zeros(N, dtype=torch.float32, device="cuda")
+    _, itl, hl = lib.conjugate_gradient_gpu_ex(ud.data_ptr(), xl.data_ptr(), L, d, index_mode=0, maxit=30, hist_len=30)
+    _, itm, hm = lib.conjugate_gradient_gpu_ex(umd.data_ptr(), xm.data_ptr(), L, d, index_mode=2, maxit=30, hist_len=30)
+    assert itl == itm == 30
+    assert np.allclose(hl, hm, rtol=1e-4)
+    assert rel_l2(xm.cpu().numpy()[perm], xl.cpu().numpy()) <= 1e-4
+
+
+def test_mixed_precision_3d(lib):
+    """Outer fp64 CG + inner float GPU CG on 64^3: residual far below what float alone reaches."""
+    L, d = 64, 3
+    N = L ** d
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    xt = torch.rand([L] * d, dtype=torch.float64, device="cuda", generator=gen)
+
+    def lap(t):
+        out = 2 * d * t.clone()
+        for ax in range(d):
+            lo = [slice(None)] * d
+            hi = [slice(None)] * d
+            lo[ax], hi[ax] = slice(0, L - 1), slice(1, L)
+            out[tuple(lo)] -= t[tuple(hi)]
+            out[tuple(hi)] -= t[tuple(lo)]
+        return out
+
+    b = lap(xt).reshape(-1).contiguous()
+    x = torch.zeros_like(b)
+    outer, inner = lib.preconditioned_cg_gpu(b.data_ptr(), x.data_ptr(), L, d)   # device pointers
+    assert 1 <= outer <= 10 and len(inner) == outer
+    res = (b - lap(x.reshape([L] * d)).reshape(-1)).norm().item() / b.norm().item()
+    assert res < 1e-8
+    assert (x - xt.reshape(-1)).abs().max().item() < 1e-6
