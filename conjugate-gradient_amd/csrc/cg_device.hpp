@@ -35,6 +35,12 @@
 namespace cgamd
 {
 
+// Measurement-only switches (tools/rowsbench.hip compiles the rows kernels with parts removed
+// to price them); always 0 in the library.
+#ifndef CG_DBG
+#define CG_DBG 0
+#endif
+
 constexpr int CG_MAXD = 32;        // scalar engine
 constexpr int CG_ROWS_MAXD = 8;    // rows engine: axes 2..9
 constexpr int CG_MAX_BLOCKS = 2048;
@@ -182,7 +188,7 @@ __device__ __forceinline__ IterCtl prologue_A(const VecArgs &a, double *sh)
   CgState *st = a.st;
   const int k = st->itA;
   const int done = st->doneA;
-  const float rr = (float)block_read_sum(a.sumB, a.nB, sh);
+  const float rr = (CG_DBG & 4) ? 1.0f : (float)block_read_sum(a.sumB, a.nB, sh);
   const float rr_prev = st->rr_hist[(k + CG_HIST - 1) % CG_HIST];
   const float rr_test = (st->lagged && k > 0) ? rr_prev : rr;
   const float residue = (float)sqrt((double)rr_test);
@@ -209,7 +215,7 @@ __device__ __forceinline__ IterCtl prologue_B(const VecArgs &a, double *sh)
   c.k = st->itB;
   c.active = st->activeB != 0;
   const int done = st->doneB;
-  const float pAp = (float)block_read_sum(a.sumA, a.nA, sh);
+  const float pAp = (CG_DBG & 4) ? 1e9f : (float)block_read_sum(a.sumA, a.nA, sh);
   c.coef = st->rr_hist[c.k % CG_HIST] / pAp;
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
@@ -405,13 +411,15 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
     const long long col0 = base + (act ? x0 : g.n0 - 4u);
     const bool el = act && lane == 0 && x0 > 0;
     const bool er = act && lane == 63 && x0 + 4 < g.n0;
-    const bool edge = el || er;
+    const bool edge = (el || er) && !(CG_DBG & 1);
     const long long eoff = (lane == 0) ? -1 : 4;
     const bool rightmost = (lane == 63) || (x0 + 4 >= g.n0);
 
     // stencil input of row yy (a zero row outside the grid unless it is a ghost row)
     auto ldrow = [&](long long yy) -> float4 {
-      const bool ok = rowghost || (yy >= 0 && yy < n1);
+      const bool ok = (rowghost || (yy >= 0 && yy < n1)) && (!(CG_DBG & 16) || (yy >= y0 && yy < y1));
+      if ((CG_DBG & 16) && !ok)
+        return make_float4(0, 0, 0, 0);
       const float4 v = src.ld4(col0 + (ok ? yy : y0) * n0);
       return sel4(ok, v);
     };
@@ -456,8 +464,8 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
       }
 
       // ---- row y ---------------------------------------------------------------------
-      float lft = __shfl_up(pc.w, 1);
-      float rgt = __shfl_down(pc.x, 1);
+      float lft = (CG_DBG & 2) ? 0.0f : __shfl_up(pc.w, 1);
+      float rgt = (CG_DBG & 2) ? 0.0f : __shfl_down(pc.x, 1);
       if (lane == 0)
         lft = ec;
       if (rightmost)
