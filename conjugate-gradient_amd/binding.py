@@ -21,7 +21,7 @@ EXPORTS = [
     "cg_solver_buffer_len", "cg_solver_ghost_offset", "cg_solver_plane", "cg_solver_create",
     "cg_solver_destroy", "cg_solver_engine", "cg_solver_blocks", "cg_solver_begin", "cg_solver_iterate",
     "cg_solver_finish", "cg_solver_sync", "cg_solver_time_kernels", "cg_solver_begin_local",
-    "cg_solver_reduce", "cg_solver_bind_sums", "cg_solver_init_state", "cg_solver_add_iterations",
+    "cg_solver_reduce", "cg_solver_bind_sums", "cg_solver_bind_partials", "cg_solver_init_state", "cg_solver_add_iterations",
     "cg_solver_kernel_A", "cg_solver_kernel_B", "cg_solver_r", "cg_solver_p",
 ]
 
@@ -115,6 +115,8 @@ class Library:
         c.cg_solver_reduce.restype = None
         c.cg_solver_bind_sums.argtypes = [vp, vp, vp]
         c.cg_solver_bind_sums.restype = None
+        c.cg_solver_bind_partials.argtypes = [vp, vp, vp]
+        c.cg_solver_bind_partials.restype = None
         c.cg_solver_init_state.argtypes = [vp, C.c_double, i32, i32]
         c.cg_solver_init_state.restype = None
         c.cg_solver_add_iterations.argtypes = [vp, i32]
@@ -247,6 +249,9 @@ class Solver:
 
     def bind_sums(self, pAp, rr):
         self.lib.c.cg_solver_bind_sums(self.h, _ptr(pAp), _ptr(rr))
+
+    def bind_partials(self, pAp_parts, rr_parts):
+        self.lib.c.cg_solver_bind_partials(self.h, _ptr(pAp_parts), _ptr(rr_parts))
 
     def init_state(self, rel, lagged, maxit):
         self.lib.c.cg_solver_init_state(self.h, rel, lagged, maxit)

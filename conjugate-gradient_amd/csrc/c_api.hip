@@ -390,6 +390,10 @@ extern "C" void cg_solver_bind_sums(cg_solver *s, const double *pAp, const doubl
 {
   s->impl.bind_sums(pAp, 1, rr, 1);
 }
+extern "C" void cg_solver_bind_partials(cg_solver *s, double *pAp_parts, double *rr_parts)
+{
+  s->impl.bind_partials(pAp_parts, rr_parts);
+}
 extern "C" void cg_solver_init_state(cg_solver *s, double rel, int lagged, int maxit)
 {
   s->impl.init_state(rel, lagged, maxit);

@@ -280,8 +280,10 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   CG_REQUIRE(((uintptr_t)r_ % 16) == 0 && ((uintptr_t)p0_ % 16) == 0 && ((uintptr_t)p1_ % 16) == 0,
              "solver buffers must be 16-byte aligned");
   const size_t np = 2 * CG_MAX_BLOCKS;
-  CHECK(hipMalloc((void **)&partA_, np * sizeof(double)));
-  CHECK(hipMalloc((void **)&partB_, np * sizeof(double)));
+  CHECK(hipMalloc((void **)&partA_own_, np * sizeof(double)));
+  CHECK(hipMalloc((void **)&partB_own_, np * sizeof(double)));
+  partA_ = partA_own_;
+  partB_ = partB_own_;
   CHECK(hipMalloc((void **)&st_, sizeof(CgState)));
   CHECK(hipHostMalloc((void **)&st_host_, sizeof(CgState)));
   CHECK(hipMemsetAsync(st_, 0, sizeof(CgState), stream_));
@@ -311,8 +313,8 @@ Solver::~Solver()
     (void)hipFree(p0_base_);
   if (own_p1_)
     (void)hipFree(p1_base_);
-  (void)hipFree(partA_);
-  (void)hipFree(partB_);
+  (void)hipFree(partA_own_);
+  (void)hipFree(partB_own_);
   (void)hipFree(st_);
   (void)hipHostFree(st_host_);
   if (own_stream_)
@@ -592,6 +594,13 @@ void Solver::bind_sums(const double *sumA, int nA, const double *sumB, int nB)
     CHECK(hipGraphExecDestroy(graph_));
     graph_ = nullptr;
   }
+}
+
+void Solver::bind_partials(double *partA, double *partB)
+{
+  partA_ = partA ? partA : partA_own_;
+  partB_ = partB ? partB : partB_own_;
+  bind_sums(nullptr, 0, nullptr, 0);
 }
 
 void Solver::init_state(double rel, int lagged, int maxit)

@@ -72,6 +72,9 @@ public:
   void begin_local(const float *b_dev, float *x_dev);         // r = b, p0 = 0, partials(1) = local r.r
   void reduce_partials(int which, double *out_dev);           // out[0] = sum of partials(which)
   void bind_sums(const double *sumA, int nA, const double *sumB, int nB);
+  // per-workgroup partials go to (and the sums are read from) caller-owned arrays of blocks() doubles,
+  // so that the caller can all-reduce them element-wise instead of reducing first
+  void bind_partials(double *partA, double *partB);
   void init_state(double rel, int lagged, int maxit);         // from the bound r.r sum
   void add_iterations(int n);                                 // maxit = it + n
   void launch_A();
@@ -94,6 +97,7 @@ private:
   float *r_base_ = nullptr, *p0_base_ = nullptr, *p1_base_ = nullptr;
   float *r_ = nullptr, *p0_ = nullptr, *p1_ = nullptr, *x_ = nullptr;
   double *partA_ = nullptr, *partB_ = nullptr;
+  double *partA_own_ = nullptr, *partB_own_ = nullptr;
   const double *sumA_ = nullptr, *sumB_ = nullptr;
   int nA_ = 0, nB_ = 0;
   CgState *st_ = nullptr;

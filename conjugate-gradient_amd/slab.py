@@ -5,8 +5,9 @@ iteration the ranks exchange
 
   * one hyperplane of r with each neighbour (the only vector whose neighbours' values are
     needed: kernel A rebuilds p = r + beta*p on its ghost planes locally), and
-  * two scalars, p.Ap and r.r, by all-reduce of device doubles; alpha and beta are then
-    derived on every rank's device from identical bits, so all ranks take the same path.
+  * the two dot products p.Ap and r.r, by all-reduce of the kernels' per-workgroup partial sums
+    (a few KiB of device doubles, no separate reduction launch); alpha and beta are then derived
+    on every rank's device from identical bits, so all ranks take the same path.
 
 Everything is enqueued asynchronously on the current stream; the host never waits inside
 the loop.  The compute steps are the HIP library's kernels (binding.Solver); a different
@@ -32,7 +33,9 @@ class HipSlabOps:
         self.r_buf = torch.zeros(self.buffer_len, dtype=torch.float32, device=device)
         self.p0_buf = torch.zeros(self.buffer_len, dtype=torch.float32, device=device)
         self.p1_buf = torch.zeros(self.buffer_len, dtype=torch.float32, device=device)
-        self.dots = torch.zeros(2, dtype=torch.float64, device=device)  # [p.Ap, r.r]
+        # per-workgroup partials of [p.Ap, r.r]: all-reduced element-wise across ranks, then summed
+        # in a fixed order by every workgroup of the consuming kernel
+        self.parts = torch.zeros(2, 4096, dtype=torch.float64, device=device)
         # kernels and collectives share one non-default stream: torch orders its RCCL work
         # against the stream that is current when a collective is issued
         self.stream = torch.cuda.Stream(device)
@@ -40,7 +43,8 @@ class HipSlabOps:
         self.solver = lib.make_solver(extents, 0, has_lo, has_hi, stream=self.stream.cuda_stream,
                                       r_buf=self.r_buf.data_ptr(), p0_buf=self.p0_buf.data_ptr(),
                                       p1_buf=self.p1_buf.data_ptr())
-        self.solver.bind_sums(self.dots[0:1].data_ptr(), self.dots[1:2].data_ptr())
+        self.solver.bind_partials(self.parts[0].data_ptr(), self.parts[1].data_ptr())
+        self.nparts = self.solver.blocks
 
     def stream_ctx(self):
         return torch.cuda.stream(self.stream)
@@ -50,8 +54,9 @@ class HipSlabOps:
         self.stream.wait_stream(torch.cuda.default_stream(self.device))
         self.solver.begin_local(b.data_ptr(), x.data_ptr())
 
-    def reduce(self, which):
-        self.solver.reduce(which, self.dots[which:which + 1].data_ptr())
+    def sum_tensor(self, which):
+        """The tensor whose element-wise sum over ranks the next kernel consumes."""
+        return self.parts[which, :self.nparts]
 
     def init_state(self, rel, lagged, maxit):
         self.solver.init_state(rel, lagged, maxit)
@@ -123,9 +128,9 @@ class SlabCG:
             req.wait()
 
     def allreduce(self, which):
-        self.ops.reduce(which)
+        t = self.ops.sum_tensor(which)
         if self.world > 1:
-            dist.all_reduce(self.ops.dots[which:which + 1], op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     # -- solve --------------------------------------------------------------------------
     def _ctx(self):

@@ -108,7 +108,7 @@ extern "C"
     float *r_buf;          /* optional caller-owned buffers of cg_solver_buffer_len() */
     float *p0_buf;         /*   floats (16-byte aligned device memory); NULL = allocate. */
     float *p1_buf;         /*   Layout: [pad | lo ghost plane | N owned | hi ghost plane] */
-    int engine;            /* 0 auto, 1 rows (vectorised), 2 scalar */
+    int engine;            /* 0 auto, 1 rows, 2 scalar, 3 planes (3-D), 4 Morton quads */
   } cg_solver_desc;
 
   size_t cg_solver_buffer_len(const cg_solver_desc *desc);   /* floats per buffer */
@@ -136,6 +136,10 @@ extern "C"
   void cg_solver_begin_local(cg_solver *s, const float *b, float *x);   /* r = b, p = 0, local r.r partials */
   void cg_solver_reduce(cg_solver *s, int which, double *out);          /* out[0] = local p.Ap (0) or r.r (1) */
   void cg_solver_bind_sums(cg_solver *s, const double *pAp, const double *rr); /* all-reduced values */
+  /* alternative to reduce + bind_sums: the kernels write their cg_solver_blocks() per-workgroup
+   * partials into caller-owned device arrays and read the sums back from them, so the caller
+   * all-reduces the arrays element-wise and no separate reduction launch is needed */
+  void cg_solver_bind_partials(cg_solver *s, double *pAp_parts, double *rr_parts);
   void cg_solver_init_state(cg_solver *s, double rel, int lagged, int maxit);
   void cg_solver_add_iterations(cg_solver *s, int n);
   void cg_solver_kernel_A(cg_solver *s);

@@ -72,8 +72,9 @@ class FakeSlabOps:
         rr = self.r_buf[g:g + n].numpy().astype(np.float64)
         self.part[1] = float(np.dot(rr, rr))
 
-    def reduce(self, which):
+    def sum_tensor(self, which):
         self.dots[which] = self.part[which]
+        return self.dots[which:which + 1]
 
     def init_state(self, rel, lagged, maxit):
         rr = np.float32(self.dots[1].item())

@@ -26,12 +26,10 @@ def run_virtual(pkg, lib, L, d, nranks, b, iters, engine=0):
         torch.cuda.synchronize()
 
     def allreduce(which):
-        for o in slabs:
-            o.reduce(which)
         sync()
-        tot = sum(o.dots[which].item() for o in slabs)  # python floats: fixed rank order
+        tot = sum(o.sum_tensor(which) for o in slabs)  # element-wise, fixed rank order
         for o in slabs:
-            o.dots[which] = tot
+            o.sum_tensor(which).copy_(tot)
         sync()
 
     def exchange():

@@ -23,8 +23,7 @@ def timed(label, f, n=200):
 o = s.ops
 with o.stream_ctx():
     timed("kernel_A", o.kernel_A)
-    timed("reduce", lambda: o.reduce(0))
-    timed("all_reduce(1 rank)", lambda: dist.all_reduce(o.dots[0:1]))
+    timed("all_reduce(1 rank)", lambda: dist.all_reduce(o.sum_tensor(0)))
     timed("iterate(1) eager", lambda: s.iterate(1))
     # graph capture of one iteration including a collective
     try:
@@ -32,7 +31,7 @@ with o.stream_ctx():
         o.add_iterations(10**6)
         with torch.cuda.graph(g, stream=o.stream):
             for _ in range(10):
-                o.kernel_A(); o.reduce(0); dist.all_reduce(o.dots[0:1]); o.kernel_B(); o.reduce(1); dist.all_reduce(o.dots[1:2])
+                o.kernel_A(); dist.all_reduce(o.sum_tensor(0)); o.kernel_B(); dist.all_reduce(o.sum_tensor(1))
         timed("graph replay (10 iterations)", g.replay, 50)
     except Exception as e:
         print("graph capture failed:", repr(e)[:300])
