@@ -420,6 +420,11 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
       const bool ok = (rowghost || (yy >= 0 && yy < n1)) && (!(CG_DBG & 16) || (yy >= y0 && yy < y1));
       if ((CG_DBG & 16) && !ok)
         return make_float4(0, 0, 0, 0);
+      if constexpr (D == 1)
+      {
+        if (!ok) // a 1-D grid has a single row: nothing above or below to fetch
+          return make_float4(0, 0, 0, 0);
+      }
       const float4 v = src.ld4(col0 + (ok ? yy : y0) * n0);
       return sel4(ok, v);
     };
@@ -458,9 +463,11 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
       float4 xn = zero4, rn = zero4;
       if constexpr (MODE == MODE_B)
       {
-        const long long yn = y + 1 < y1 ? y + 1 : y1 - 1;
-        xn = load4<NT>(a.x + col0 + yn * n0);
-        rn = load4<false>(a.r + col0 + yn * n0);
+        if (y + 1 < y1) // wave-uniform
+        {
+          xn = load4<NT>(a.x + col0 + (y + 1) * n0);
+          rn = load4<false>(a.r + col0 + (y + 1) * n0);
+        }
       }
 
       // ---- row y ---------------------------------------------------------------------
