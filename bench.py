@@ -80,6 +80,21 @@ def measured_traffic(workload, kernel_mode):
     return None
 
 
+def cpu_baseline_c1():
+    """Config 1 of the baseline list as is: 1-D N = 2^20, fp64, the oracle's conjugate_gradient for
+    K = 20 iterations on one core (the reference loop has no cap and would need O(N) iterations)."""
+    import numpy as np
+    from oracle import oracle as orc
+    o = orc.Oracle(native=True)
+    n = 1 << 20
+    b = np.random.default_rng(1234).random(n)
+    t0 = time.perf_counter()
+    _, _, done, _ = o.conjugate_gradient(b, n, 1, max_iters=20)
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{done} fp64 CG iterations, 1-D N=2^20 ({dt:.2f} s)"}
+
+
 def cpu_baseline(ext, budget_s):
     """Oracle restatement of conjugate_gradient (cpu.cu:216-261), fp64, 1 thread, -O3 -march=native.
     Bounded sample: a square/cubic sub-grid of the workload's dimension sized so the run takes
@@ -219,6 +234,7 @@ def main():
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ext, args.cpu_seconds)
+            out["cpu_baseline_1d_2e20"] = cpu_baseline_c1()
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -9,7 +9,7 @@ import os
 import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libconjugate_gradient_gpu.so")
+LIB_PATH = os.environ.get("CG_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libconjugate_gradient_gpu.so")
 
 EXPORTS = [
     # part 1: the reference's symbols

@@ -95,13 +95,16 @@ unsigned long long grid_points(int L, int d)
 // benchmarks) reuse r/p buffers and the captured graph
 struct Cache
 {
-  int L = 0, d = 0, mode = -1;
+  int L = 0, d = 0, mode = -1, device = -1;
   std::unique_ptr<Solver> solver;
   Solver &get(int L_, int d_, int mode_)
   {
     const int m = mode_ == 2 ? 2 : 0;
-    if (!solver || L != L_ || d != d_ || mode != m)
+    int dev = 0;
+    CHECK(hipGetDevice(&dev));
+    if (!solver || L != L_ || d != d_ || mode != m || device != dev)
     {
+      device = dev;
       solver.reset();
       SolverDesc desc;
       desc.d = d_;

@@ -146,14 +146,20 @@ __global__ void __launch_bounds__(256) k_morton4(const MortonGeom g, const VecAr
 // that is r + beta*p, formed once per point), then every quad takes the neighbour quads that
 // lie inside the tile from LDS and only the others (one face per axis and direction) from
 // memory.  Two LDS buffers alternate, so one barrier per tile suffices.
-constexpr unsigned CG_MORTON_TILE_BITS = 12;
+#ifndef CG_MORTON_TILE_BITS_DEF
+#define CG_MORTON_TILE_BITS_DEF 12
+#endif
+#ifndef CG_MORTON_NBUF
+#define CG_MORTON_NBUF 2
+#endif
+constexpr unsigned CG_MORTON_TILE_BITS = CG_MORTON_TILE_BITS_DEF;
 constexpr unsigned CG_MORTON_TILE = 1u << CG_MORTON_TILE_BITS;
 
 template <int MODE, int POL>
 __global__ void __launch_bounds__(256) k_morton_tile(const MortonGeom g, const VecArgs a)
 {
   __shared__ double sh[8];
-  __shared__ float4 tile[2][CG_MORTON_TILE / 4];
+  __shared__ float4 tile[CG_MORTON_NBUF][CG_MORTON_TILE / 4];
   constexpr bool NT = POL == POL_KEEP_R;
   constexpr int QPT = CG_MORTON_TILE / 4 / 256; // quads per thread and tile
   Src<MODE, POL_PLAIN> src;
@@ -193,7 +199,7 @@ __global__ void __launch_bounds__(256) k_morton_tile(const MortonGeom g, const V
   for (unsigned t = t0; t < t1; t++)
   {
     const unsigned base = t << CG_MORTON_TILE_BITS;
-    float4(&buf)[CG_MORTON_TILE / 4] = tile[t & 1];
+    float4(&buf)[CG_MORTON_TILE / 4] = tile[CG_MORTON_NBUF == 2 ? (t & 1) : 0];
     float4 c[QPT], xv[QPT], rv[QPT];
 #pragma unroll
     for (int s = 0; s < QPT; s++)
@@ -282,6 +288,8 @@ __global__ void __launch_bounds__(256) k_morton_tile(const MortonGeom g, const V
         acc = fmaf(ro.w, ro.w, acc);
       }
     }
+    if (CG_MORTON_NBUF == 1)
+      __syncthreads(); // the single buffer is overwritten by the next tile
   }
   if constexpr (MODE != MODE_STENCIL)
     block_write_partial(acc, a.part_out, sh);

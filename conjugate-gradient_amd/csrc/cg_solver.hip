@@ -135,7 +135,7 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
   g.n1 = d >= 2 ? n[1] : 1;
   const unsigned lanes = n[0] / 4;
   block = (int)std::min(256u, (lanes + 63) / 64 * 64);
-  block = env_int("CG_ROWS_BLOCK", block);
+  block = std::max(64, std::min(256, env_int("CG_ROWS_BLOCK", block) / 64 * 64)); // k_rows is bounded to 256 threads
   g.nxc = (lanes + block - 1) / block;
   unsigned long long ncols = g.nxc, stride = (unsigned long long)n[0] * g.n1;
   for (int k = 2; k < d; k++)
@@ -355,7 +355,7 @@ void Solver::build_geometry()
 
   const bool rows_ok = layout_ == LAYOUT_LEX && (n[0] % 4 == 0) && d <= CG_ROWS_MAXD + 2;
   const bool planes_ok = rows_ok && d == 3;
-  const bool morton4_ok = layout_ == LAYOUT_MORTON && d >= 2;
+  const bool morton4_ok = layout_ == LAYOUT_MORTON && d >= 2 && N_ >= 4 && N_ % 4 == 0;
   engine_ = desc_.engine == ENGINE_AUTO
                 ? (planes_ok ? ENGINE_PLANES : (rows_ok ? ENGINE_ROWS : (morton4_ok ? ENGINE_MORTON4 : ENGINE_SCALAR)))
                 : desc_.engine;
@@ -778,7 +778,7 @@ void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode
       for (unsigned v = L; v > 1; v >>= 1)
         bits++;
       CG_REQUIRE(is_pow2(L) && bits * d <= 32 && sg.N < (1ull << 32), "the Morton layout needs L = 2^m with m*d < 32");
-      if (d >= 2 && aligned)
+      if (d >= 2 && aligned && sg.N >= 4 && sg.N % 4 == 0)
       {
         MortonGeom g;
         int block = 256, grid = 1;
@@ -797,13 +797,19 @@ void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode
 
 double dot_device(const float *v, const float *w, unsigned long long n, hipStream_t stream)
 {
-  static double *part = nullptr;
-  static double *host = nullptr;
-  if (!part)
+  // scratch for the partials, one set per device, kept for the life of the process
+  constexpr int MAXDEV = 64;
+  static double *part_of[MAXDEV] = {nullptr};
+  static double *host_of[MAXDEV] = {nullptr};
+  int dev = 0;
+  CHECK(hipGetDevice(&dev));
+  CG_REQUIRE(dev >= 0 && dev < MAXDEV, "device ordinal out of range");
+  if (!part_of[dev])
   {
-    CHECK(hipMalloc((void **)&part, (2 * CG_MAX_BLOCKS + 1) * sizeof(double)));
-    CHECK(hipHostMalloc((void **)&host, sizeof(double)));
+    CHECK(hipMalloc((void **)&part_of[dev], (2 * CG_MAX_BLOCKS + 1) * sizeof(double)));
+    CHECK(hipHostMalloc((void **)&host_of[dev], sizeof(double)));
   }
+  double *part = part_of[dev], *host = host_of[dev];
   const unsigned long long nb = (n / 4 + 255) / 256 + 1;
   const int grid = (int)std::min<unsigned long long>(nb, (unsigned long long)max_blocks());
   launch_dot(v, w, n, part, grid, stream);

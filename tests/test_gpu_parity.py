@@ -464,3 +464,15 @@ def test_reference_kernel_names_via_compat_launch(lib, oracle):
         lib.laplace_gpu_jl(out.data_ptr(), ud.data_ptr(), 0.0, d, L, N, mode, 2, 128)   # covers 256 of 512 points
         got = out.cpu().numpy()
         assert np.array_equal(got[:256], want[:256]) and np.all(got[256:] == 9.0)
+
+
+def test_cpp_drivers_built_against_the_library(pkg):
+    """lib/tests: the assert-based C++ executable that launches the reference-named kernels with
+    its own shapes on managed fields (in the manner of tests.cu:327-525)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "tests")
+    if not os.path.exists(exe):
+        pytest.skip("drivers not built (make -C conjugate-gradient_amd drivers)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "tests passed!" in out.stdout

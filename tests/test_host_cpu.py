@@ -91,3 +91,22 @@ def test_host_pcg_bitwise_equals_reference_fixture(lib, capfd):
     C.CDLL(None).fflush(None)  # the library prints through C stdio
     out = capfd.readouterr().out
     assert "number of steps (outer) 4" in out and out.count("number of steps inner") == 4
+
+
+def test_neighbour_index_random_samples_at_config_sizes(lib, oracle):
+    """Host entry point against the oracle at the benchmark grids (lexicographic and Morton)."""
+    rng = np.random.default_rng(99)
+    for L, d in [(8192, 2), (1024, 3), (512, 3), (128, 4), (1 << 20, 1)]:
+        N = L ** d
+        for ind in rng.integers(0, N, 300).tolist() + [0, N - 1, L - 1, L, N - L]:
+            for k in range(d):
+                for a in (-1, 0, 1):
+                    want = oracle.neighbour_index_gpu(ind, k, a, L, d, N, 0)
+                    assert lib.neighbour_index_gpu(ind, k, a, L, d, N, 0) == want
+    L, d = 128, 4
+    N = L ** d
+    for ind in rng.integers(0, N, 500).tolist() + [0, N - 1, 0x9999d9d]:
+        for k in range(d):
+            for a in (-1, 1):
+                nb = oracle.morton_neighbour(ind, d, k, a)
+                assert lib.neighbour_index_gpu(ind, k, a, L, d, N, 2) == (nb if nb < N else N)
