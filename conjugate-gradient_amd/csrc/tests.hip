@@ -75,6 +75,20 @@ static void test_laplace_1d(bool sine)
   cg_free_field(u);
 }
 
+// tests.cu:447-464: 100^4 points of zeros through the one-point-per-thread kernel on managed
+// fields must not fault (the reference added it after an illegal access seen from Julia)
+static void test_laplace_large()
+{
+  unsigned int L = 100, d = 4, N = 100000000u;
+  float *ddf = cuda_allocate_field((int)N);
+  float *u = cuda_allocate_field((int)N);
+  laplace_gpu<<<(N + 255) / 256, 256>>>(ddf, u, d, L, N, 0);
+  OK(hipDeviceSynchronize());
+  assert(ddf[0] == 0.0f && ddf[N - 1] == 0.0f);
+  cg_free_field(ddf);
+  cg_free_field(u);
+}
+
 static void test_muladd()
 {
   int N = 777;
@@ -133,6 +147,7 @@ int main()
   test_laplace_1d(true);
   test_laplace_1d(false);
   test_muladd();
+  test_laplace_large();
   assert(test_cg_gpu(10, 2, 100));
   printf("tests passed!\n");
   return 0;
