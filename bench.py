@@ -96,7 +96,7 @@ def cpu_baseline_c1():
 
 
 def cpu_baseline(ext, budget_s):
-    """Oracle restatement of conjugate_gradient (cpu.cu:216-261), fp64, 1 thread, -O3 -march=native.
+    """Oracle restatement of conjugate_gradient (cpu.cu:216-261), fp64, 1 thread, -O3 -march=x86-64-v3.
     Bounded sample: a square/cubic sub-grid of the workload's dimension sized so the run takes
     roughly budget_s; iterations/s is scaled to the workload's point count (cost is linear in
     points: the stencil's index arithmetic dominates)."""
@@ -126,6 +126,23 @@ def cpu_baseline(ext, budget_s):
     return {"value": its_per_s_sample * n / n_full, "unit": "iterations/s", "cores": 1, "kind": "port",
             "sample": f"{done} fp64 CG iterations on a {L}^{d} grid ({n} points, {dt:.1f} s), "
                       f"scaled by points to the {'x'.join(map(str, ext))} workload"}
+
+
+def cpu_baselines_isolated(ext, budget_s):
+    """Run the CPU legs in a child process: a host-side failure there (e.g. an instruction the
+    box's CPU lacks) must not take the GPU result down with it."""
+    import subprocess
+    code = ("import json,sys; sys.path.insert(0, %r); import bench; "
+            "print(json.dumps({'cpu_baseline': bench.cpu_baseline(%r, %r), "
+            "'cpu_baseline_1d_2e20': bench.cpu_baseline_c1()}))" % (ROOT, list(ext), float(budget_s)))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        if r.returncode == 0:
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        err = f"exit {r.returncode}: {r.stderr[-300:]}"
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+    return {"cpu_baseline": {"value": None, "unit": "iterations/s", "cores": 1, "kind": "port", "sample": "failed: " + err}}
 
 
 def main():
@@ -233,8 +250,7 @@ def main():
         if roof:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ext, args.cpu_seconds)
-            out["cpu_baseline_1d_2e20"] = cpu_baseline_c1()
+            out.update(cpu_baselines_isolated(ext, args.cpu_seconds))
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -33,10 +33,10 @@ def _load(name):
 
 
 class Oracle:
-    """The restatement.  native=True loads the -O3 -march=native timing build."""
+    """The restatement.  native=True loads the -O3 -march=x86-64-v3 timing build."""
 
     def __init__(self, native=False):
-        name = "libcg_oracle_native.so" if native else "libcg_oracle.so"
+        name = "libcg_oracle_opt.so" if native else "libcg_oracle.so"
         lib = _load(name)
         if lib is None:
             build()
