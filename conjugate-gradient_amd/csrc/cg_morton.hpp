@@ -21,6 +21,7 @@ struct MortonGeom
   int d;
   unsigned long long N;
   unsigned mmask[CG_MAXD];
+  int interleave; // tile order of the tiled kernel: 0 contiguous range per workgroup, 1 XCD-chunked round-robin
 };
 
 template <int MODE, int POL>
@@ -149,6 +150,9 @@ __global__ void __launch_bounds__(256) k_morton4(const MortonGeom g, const VecAr
 #ifndef CG_MORTON_TILE_BITS_DEF
 #define CG_MORTON_TILE_BITS_DEF 12
 #endif
+#ifndef CG_MORTON_BT
+#define CG_MORTON_BT 256
+#endif
 #ifndef CG_MORTON_NBUF
 #define CG_MORTON_NBUF 2
 #endif
@@ -156,12 +160,12 @@ constexpr unsigned CG_MORTON_TILE_BITS = CG_MORTON_TILE_BITS_DEF;
 constexpr unsigned CG_MORTON_TILE = 1u << CG_MORTON_TILE_BITS;
 
 template <int MODE, int POL>
-__global__ void __launch_bounds__(256) k_morton_tile(const MortonGeom g, const VecArgs a)
+__global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g, const VecArgs a)
 {
-  __shared__ double sh[8];
+  __shared__ double sh[CG_MORTON_BT / 64 < 8 ? 8 : CG_MORTON_BT / 64];
   __shared__ float4 tile[CG_MORTON_NBUF][CG_MORTON_TILE / 4];
   constexpr bool NT = POL == POL_KEEP_R;
-  constexpr int QPT = CG_MORTON_TILE / 4 / 256; // quads per thread and tile
+  constexpr int QPT = CG_MORTON_TILE / 4 / CG_MORTON_BT; // quads per thread and tile
   Src<MODE, POL_PLAIN> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
@@ -192,19 +196,31 @@ __global__ void __launch_bounds__(256) k_morton_tile(const MortonGeom g, const V
   const float4 zero4 = make_float4(0, 0, 0, 0);
   const unsigned N = (unsigned)g.N;
   const unsigned ntiles = N >> CG_MORTON_TILE_BITS;
-  const unsigned t0 = (unsigned)((unsigned long long)blockIdx.x * ntiles / gridDim.x);
-  const unsigned t1 = (unsigned)((unsigned long long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  unsigned t0 = (unsigned)((unsigned long long)blockIdx.x * ntiles / gridDim.x);
+  unsigned t1 = (unsigned)((unsigned long long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  unsigned tstep = 1;
+  if (g.interleave && gridDim.x % 8 == 0 && ntiles % 8 == 0)
+  {
+    // workgroups b, b+8, ... share an XCD (round-robin dispatch): give each XCD one eighth of the
+    // Z-curve and let its workgroups sweep it side by side, so that the tiles in flight are
+    // neighbours and their faces meet in that XCD's L2
+    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per = gridDim.x >> 3, chunk = ntiles >> 3;
+    t0 = xcd * chunk + j;
+    t1 = (xcd + 1) * chunk;
+    tstep = per;
+  }
   const unsigned m0 = g.mmask[0], m1 = g.mmask[1];
 
-  for (unsigned t = t0; t < t1; t++)
+  unsigned par = 0;
+  for (unsigned t = t0; t < t1; t += tstep, par ^= 1u)
   {
     const unsigned base = t << CG_MORTON_TILE_BITS;
-    float4(&buf)[CG_MORTON_TILE / 4] = tile[CG_MORTON_NBUF == 2 ? (t & 1) : 0];
+    float4(&buf)[CG_MORTON_TILE / 4] = tile[CG_MORTON_NBUF == 2 ? par : 0];
     float4 c[QPT], xv[QPT], rv[QPT];
 #pragma unroll
     for (int s = 0; s < QPT; s++)
     {
-      const unsigned ql = threadIdx.x + 256u * s;
+      const unsigned ql = threadIdx.x + (unsigned)CG_MORTON_BT * s;
       const unsigned i = base + (ql << 2);
       c[s] = src.ld4((long long)i);
       if constexpr (MODE == MODE_B)
@@ -215,7 +231,7 @@ __global__ void __launch_bounds__(256) k_morton_tile(const MortonGeom g, const V
     }
 #pragma unroll
     for (int s = 0; s < QPT; s++)
-      buf[threadIdx.x + 256u * s] = c[s];
+      buf[threadIdx.x + (unsigned)CG_MORTON_BT * s] = c[s];
     __syncthreads();
 
     // quad holding index j: LDS if j is in this tile, memory otherwise, zero outside the grid
@@ -231,7 +247,7 @@ __global__ void __launch_bounds__(256) k_morton_tile(const MortonGeom g, const V
 #pragma unroll
     for (int s = 0; s < QPT; s++)
     {
-      const unsigned ql = threadIdx.x + 256u * s;
+      const unsigned ql = threadIdx.x + (unsigned)CG_MORTON_BT * s;
       const unsigned i = base + (ql << 2);
       const float4 cc = c[s];
       const float4 xp = quad(morton_inc(i + 1u, m0));

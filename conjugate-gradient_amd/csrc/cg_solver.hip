@@ -205,10 +205,11 @@ static void make_morton_geom(int d, unsigned long long N, MortonGeom &g, int &bl
   g.N = N;
   for (int k = 0; k < d; k++)
     g.mmask[k] = morton_mask(d, k);
+  g.interleave = env_int("CG_MORTON_INTERLEAVE", 1);
   block = 256;
   const unsigned long long quads = N / 4;
   const unsigned long long want = (quads + block - 1) / block;
-  grid = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(want, (unsigned long long)std::min(env_int("CG_MORTON_BLOCKS", 2 * CG_MAX_BLOCKS), 2 * CG_MAX_BLOCKS)));
+  grid = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(want, (unsigned long long)std::min(env_int("CG_MORTON_BLOCKS", CG_MAX_BLOCKS), 2 * CG_MAX_BLOCKS)));
   // with at least one LDS tile per workgroup the tiled kernel is used: never more workgroups than tiles
   if (N % CG_MORTON_TILE == 0 && N / CG_MORTON_TILE >= 64)
     grid = (int)std::min<unsigned long long>((unsigned long long)grid, N / CG_MORTON_TILE);
@@ -450,9 +451,9 @@ static void launch_morton4(const MortonGeom &g, const VecArgs &a, int grid, int 
   if (tiled)
   {
     if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
-      hipLaunchKernelGGL((k_morton_tile<MODE, POL_KEEP_R>), dim3(grid), dim3(block), 0, s, g, a);
+      hipLaunchKernelGGL((k_morton_tile<MODE, POL_KEEP_R>), dim3(grid), dim3(CG_MORTON_BT), 0, s, g, a);
     else
-      hipLaunchKernelGGL((k_morton_tile<MODE, POL_PLAIN>), dim3(grid), dim3(block), 0, s, g, a);
+      hipLaunchKernelGGL((k_morton_tile<MODE, POL_PLAIN>), dim3(grid), dim3(CG_MORTON_BT), 0, s, g, a);
   }
   else if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
     hipLaunchKernelGGL((k_morton4<MODE, POL_KEEP_R>), dim3(grid), dim3(block), 0, s, g, a);

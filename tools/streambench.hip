@@ -117,6 +117,15 @@ __global__ void __launch_bounds__(256) k_cgB(float4 *x, float4 *r, const float4 
   }
 }
 
+__global__ void k_rand(float *p, size_t n, unsigned seed)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+  {
+    unsigned h = (unsigned)i * 0x9E3779B9u + seed; h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    p[i] = (float)(h >> 8) * (1.0f / 16777216.0f);
+  }
+}
+
 template <typename F>
 static float timeit(F f, int reps)
 {
@@ -153,7 +162,8 @@ int main()
   const unsigned L = 8192; const size_t n = (size_t)L * L, n4 = n / 4;
   float4 *a, *b, *c, *d;
   CK(hipMalloc(&a, n * 4)); CK(hipMalloc(&b, n * 4)); CK(hipMalloc(&c, n * 4)); CK(hipMalloc(&d, n * 4));
-  CK(hipMemset(a, 0, n * 4)); CK(hipMemset(b, 0, n * 4)); CK(hipMemset(c, 0, n * 4)); CK(hipMemset(d, 0, n * 4));
+  if (getenv("SB_RANDOM")) { k_rand<<<2048, 256>>>((float *)a, n, 1); k_rand<<<2048, 256>>>((float *)b, n, 2); k_rand<<<2048, 256>>>((float *)c, n, 3); k_rand<<<2048, 256>>>((float *)d, n, 4); CK(hipDeviceSynchronize()); }
+  else { CK(hipMemset(a, 0, n * 4)); CK(hipMemset(b, 0, n * 4)); CK(hipMemset(c, 0, n * 4)); CK(hipMemset(d, 0, n * 4)); }
   const double words[3] = {2, 3, 5};
   const char *names[3] = {"copy 1R1W", "axpy 2R1W", "upd  3R2W"};
   for (int grid : {1024})
@@ -179,7 +189,7 @@ int main()
     // a = x, b = r, c = p0, d = p1
     const unsigned bs = 256, nxc = L / 4 / bs;
     for (unsigned bpc : {128u})
-      for (int dirB : {1, -1})
+      for (int dirB : {1})
         sweep<0>(a, b, c, d, L, nxc, bpc, bs, 1, dirB, n);
   }
   return 0;
