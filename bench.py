@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--workload", default="2d-8192", help="2d-8192 | 3d-1024x128 | 3d-512 | 4d-128-morton | LxLx..[:mode]")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-slab", action="store_true", help="run the multi-rank driver even with one rank")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal: host-staged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -154,6 +155,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "CG_BENCH_DEVICE" in os.environ:  # rehearsal on a one-GPU box: every rank on the same device
+        local_rank = int(os.environ["CG_BENCH_DEVICE"])
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
@@ -161,7 +164,10 @@ def main():
     if world > 1 or args.force_slab:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     pkg = load_package()
     lib = pkg.load_library()
@@ -225,7 +231,7 @@ def main():
         assert done == args.warmup + args.steps, (done, args.warmup, args.steps)
         parallelism = f"slab{world}"
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -241,6 +247,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "local_extents": ext, "index_mode": mode,
                        "points_per_gpu": N, "parallelism": parallelism, "graph": not args.no_graph,
+                       "backend": args.backend if world > 1 else None,
                        "rhs": "u01 seed 1234+rank", "x0": 0},
             "iterations_per_sec_global": round(its, 3),
             "hbm_algorithmic_GBps": round(BYTES_ITER * N * world * its / 1e9, 1),

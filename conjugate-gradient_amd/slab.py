@@ -124,13 +124,44 @@ class SlabCG:
         if self.has_hi:
             ops.append(dist.P2POp(dist.isend, self.r_last, self._global_rank(self.rank + 1), self.group))
             ops.append(dist.P2POp(dist.irecv, self.r_ghost_hi, self._global_rank(self.rank + 1), self.group))
+        if self._host_staged(self.r_first):
+            self._exchange_r_host_staged()
+            return
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
     def allreduce(self, which):
         t = self.ops.sum_tensor(which)
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self._host_staged(t):
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    # -- rehearsal path: device tensors over a backend that only moves host memory (gloo) -----
+    # Lets several ranks share ONE GPU (RCCL refuses that) to rehearse the multi-rank flow; it
+    # synchronises with the host on every exchange and is never used with the nccl backend.
+    def _host_staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _exchange_r_host_staged(self):
+        reqs, recvs = [], []
+        if self.has_lo:
+            reqs.append(dist.isend(self.r_first.cpu(), self._global_rank(self.rank - 1), self.group))
+            buf = torch.empty(self.r_ghost_lo.shape, dtype=self.r_ghost_lo.dtype)
+            reqs.append(dist.irecv(buf, self._global_rank(self.rank - 1), self.group))
+            recvs.append((self.r_ghost_lo, buf))
+        if self.has_hi:
+            reqs.append(dist.isend(self.r_last.cpu(), self._global_rank(self.rank + 1), self.group))
+            buf = torch.empty(self.r_ghost_hi.shape, dtype=self.r_ghost_hi.dtype)
+            reqs.append(dist.irecv(buf, self._global_rank(self.rank + 1), self.group))
+            recvs.append((self.r_ghost_hi, buf))
+        for r in reqs:
+            r.wait()
+        for dst, buf in recvs:
+            dst.copy_(buf)
 
     # -- solve --------------------------------------------------------------------------
     def _ctx(self):

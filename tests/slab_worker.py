@@ -1,5 +1,8 @@
-"""Worker for the multi-process slab tests: python slab_worker.py <out.npz> <L> <d> <iters>.
-Reads RANK / WORLD_SIZE / MASTER_* from the environment (gloo, CPU)."""
+"""Worker for the multi-process slab tests: python slab_worker.py <out.npz> <L> <d> <iters> [hip].
+Reads RANK / WORLD_SIZE / MASTER_* from the environment (gloo).  Without `hip` the per-slab
+compute is the CPU stand-in; with it every rank runs the HIP kernels on cuda:0 (the ranks
+share the one GPU, the exchange is staged through host memory because RCCL refuses two
+ranks on one device)."""
 import os
 import sys
 
@@ -16,6 +19,7 @@ from fake_slab_ops import FakeSlabOps  # noqa: E402
 
 def main():
     out, L, d, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    hip = len(sys.argv) > 5 and sys.argv[5] == "hip"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg = load_package()
@@ -31,10 +35,17 @@ def main():
     n_loc = N // world
     b_loc = torch.from_numpy(b[rank * n_loc:(rank + 1) * n_loc].copy())
     x_loc = torch.zeros(n_loc, dtype=torch.float32)
-    s = SlabCG(None, ext, make_ops=lambda e, lo, hi: FakeSlabOps(e, lo, hi))
+    if hip:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        b_loc, x_loc = b_loc.to(dev), x_loc.to(dev)
+        s = SlabCG(pkg.load_library(), ext, device=dev)
+    else:
+        s = SlabCG(None, ext, make_ops=lambda e, lo, hi: FakeSlabOps(e, lo, hi))
     s.begin(b_loc, x_loc, 1e-6, 1)
     s.iterate(iters)
     n, res, hist = s.finish(hist_len=iters)
+    x_loc = x_loc.cpu()
     gathered = [torch.zeros(n_loc, dtype=torch.float32) for _ in range(world)]
     dist.all_gather(gathered, x_loc)
     if rank == 0:

@@ -2,6 +2,10 @@
 ghost planes are copied by hand and the dot products summed on the host.  This exercises
 exactly what each rank runs under torch.distributed (ghost-plane reads in both kernels, the
 local rebuild of p on ghost planes, all-reduced scalars through bind_sums)."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -86,3 +90,43 @@ def test_virtual_ranks_match_single_gpu_and_oracle(pkg, lib, oracle, L, d, nrank
     assert np.linalg.norm(x - x1.cpu().numpy()) <= 1e-5 * np.linalg.norm(xe)
     n = min(len(hist), len(h1), 8)
     assert np.allclose(hist[:n], h1[:n], rtol=1e-5)
+
+
+def run_world_hip(tmp_path, world, L, d, iters, port):
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / f"hip_w{world}_L{L}_d{d}.npz")
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "slab_worker.py"), out, str(L), str(d),
+                                       str(iters), "hip"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            log, _ = p.communicate(timeout=100)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append((p.returncode, log.decode()[-2000:]))
+    assert all(rc == 0 for rc, _ in logs), logs
+    return np.load(out)
+
+
+@pytest.mark.parametrize("L,d,world", [(64, 2, 2), (16, 3, 4)])
+def test_processes_sharing_the_gpu(tmp_path, lib, oracle, L, d, world):
+    """One process per rank through torch.distributed (SlabCG as bench.py drives it), every
+    rank's kernels on cuda:0, planes and partials exchanged over gloo."""
+    r = run_world_hip(tmp_path, world, L, d, 200, 29660 + world)
+    xe, rese, iterse, histe = oracle.cg_f32(r["b"], L, d, hist_len=200)
+    assert abs(int(r["iters"]) - iterse) <= max(2, 0.05 * iterse)
+    assert np.all(np.abs(r["x"] - r["xt"]) < 1e-3)
+    assert np.linalg.norm(r["x"] - xe) <= 1e-4 * np.linalg.norm(xe)
+    bd = torch.from_numpy(r["b"]).cuda()
+    x1 = torch.zeros(L ** d, dtype=torch.float32, device="cuda")
+    _, it1, h1 = lib.conjugate_gradient_gpu_ex(bd.data_ptr(), x1.data_ptr(), L, d, hist_len=200)
+    assert abs(int(r["iters"]) - it1) <= max(2, 0.05 * it1)
+    assert np.linalg.norm(r["x"] - x1.cpu().numpy()) <= 1e-5 * np.linalg.norm(xe)
+    n = min(len(r["hist"]), len(h1), 8)
+    assert np.allclose(r["hist"][:n], h1[:n], rtol=1e-5)
