@@ -23,6 +23,9 @@ EXPORTS = [
     "cg_solver_finish", "cg_solver_sync", "cg_solver_time_kernels", "cg_solver_begin_local",
     "cg_solver_reduce", "cg_solver_bind_sums", "cg_solver_bind_partials", "cg_solver_init_state", "cg_solver_add_iterations",
     "cg_solver_kernel_A", "cg_solver_kernel_B", "cg_solver_r", "cg_solver_p",
+    "cg_links_box_bytes", "cg_links_alloc", "cg_links_free", "cg_links_export", "cg_links_open",
+    "cg_links_close", "cg_solver_bind_links", "cg_solver_exchange", "cg_solver_links_error",
+    "cg_solver_links_times",
 ]
 
 
@@ -128,6 +131,23 @@ class Library:
         c.cg_solver_r.restype = C.c_void_p
         c.cg_solver_p.argtypes = [vp, i32]
         c.cg_solver_p.restype = C.c_void_p
+        c.cg_links_box_bytes.argtypes = [dp]
+        c.cg_links_box_bytes.restype = C.c_size_t
+        c.cg_links_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        c.cg_links_export.argtypes = [vp, C.c_char_p]
+        c.cg_links_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        for f in ("cg_links_free", "cg_links_close"):
+            getattr(c, f).argtypes = [vp]
+        for f in ("cg_links_alloc", "cg_links_free", "cg_links_export", "cg_links_open", "cg_links_close"):
+            getattr(c, f).restype = i32
+        c.cg_solver_bind_links.argtypes = [vp, i32, i32, C.POINTER(C.c_void_p)]
+        c.cg_solver_bind_links.restype = None
+        c.cg_solver_exchange.argtypes = [vp, i32, i32]
+        c.cg_solver_exchange.restype = None
+        c.cg_solver_links_error.argtypes = [vp]
+        c.cg_solver_links_error.restype = i32
+        c.cg_solver_links_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        c.cg_solver_links_times.restype = None
 
     # ---- the reference's entry points (main.jl:16-58) --------------------------------
     def conjugate_gradient_gpu(self, b, x, L, d):
@@ -167,6 +187,34 @@ class Library:
         inner = (C.c_int * 1002)()
         outer = self.c.preconditioned_cg_gpu(_ptr(b), _ptr(x), L, d, C.cast(inner, C.c_void_p), 1002, verbose)
         return outer, [v for v in inner if v][:outer + 1] if outer else []
+
+    # ---- boxes of the direct xGMI path (all raise on a HIP error) ----------------------
+    def links_alloc(self, nbytes):
+        box = C.c_void_p()
+        e = self.c.cg_links_alloc(nbytes, C.byref(box))
+        if e or not box.value:
+            raise RuntimeError(f"cg_links_alloc({nbytes}) failed with hipError {e}")
+        return box.value
+
+    def links_free(self, box):
+        self.c.cg_links_free(_ptr(box))
+
+    def links_export(self, box):
+        buf = C.create_string_buffer(64)
+        e = self.c.cg_links_export(_ptr(box), buf)
+        if e:
+            raise RuntimeError(f"cg_links_export failed with hipError {e}")
+        return buf.raw
+
+    def links_open(self, handle):
+        box = C.c_void_p()
+        e = self.c.cg_links_open(C.create_string_buffer(bytes(handle), 64), C.byref(box))
+        if e or not box.value:
+            raise RuntimeError(f"cg_links_open failed with hipError {e}")
+        return box.value
+
+    def links_close(self, box):
+        self.c.cg_links_close(_ptr(box))
 
     def make_solver(self, extents, index_mode=0, has_lo=0, has_hi=0, stream=None, r_buf=None, p0_buf=None,
                     p1_buf=None, engine=0):
@@ -264,6 +312,26 @@ class Solver:
 
     def kernel_B(self):
         self.lib.c.cg_solver_kernel_B(self.h)
+
+    # direct xGMI path
+    def box_bytes(self):
+        return self.lib.c.cg_links_box_bytes(C.byref(self._desc))
+
+    def bind_links(self, rank, boxes):
+        """boxes: every rank's box as mapped in this process; an empty list unbinds."""
+        arr = (C.c_void_p * max(1, len(boxes)))(*[int(b) for b in boxes])
+        self.lib.c.cg_solver_bind_links(self.h, rank, len(boxes), arr)
+
+    def exchange(self, which, force=False):
+        self.lib.c.cg_solver_exchange(self.h, which, int(force))
+
+    def links_error(self):
+        return self.lib.c.cg_solver_links_error(self.h)
+
+    def links_times(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self.lib.c.cg_solver_links_times(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
 
 _LIB = None

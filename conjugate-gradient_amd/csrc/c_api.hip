@@ -406,3 +406,19 @@ extern "C" void cg_solver_kernel_A(cg_solver *s) { s->impl.launch_A(); }
 extern "C" void cg_solver_kernel_B(cg_solver *s) { s->impl.launch_B(); }
 extern "C" float *cg_solver_r(cg_solver *s) { return s->impl.r(); }
 extern "C" float *cg_solver_p(cg_solver *s, int which) { return s->impl.p(which); }
+
+// ---- direct xGMI path ------------------------------------------------------------------------
+
+extern "C" size_t cg_links_box_bytes(const cg_solver_desc *desc) { return links_box_bytes(Solver::plane_of(to_desc(desc))); }
+extern "C" int cg_links_alloc(size_t bytes, void **box) { return links_alloc(bytes, box); }
+extern "C" int cg_links_free(void *box) { return links_free(box); }
+extern "C" int cg_links_export(void *box, unsigned char *handle64) { return links_export(box, handle64); }
+extern "C" int cg_links_open(const unsigned char *handle64, void **box) { return links_open(handle64, box); }
+extern "C" int cg_links_close(void *box) { return links_close(box); }
+extern "C" void cg_solver_bind_links(cg_solver *s, int rank, int world, void *const *boxes)
+{
+  s->impl.bind_links(rank, world, boxes);
+}
+extern "C" void cg_solver_exchange(cg_solver *s, int which, int force) { s->impl.launch_exchange(which, force != 0); }
+extern "C" int cg_solver_links_error(cg_solver *s) { return s->impl.links_error(); }
+extern "C" void cg_solver_links_times(cg_solver *s, float *ms_xA, float *ms_xB) { s->impl.links_times(ms_xA, ms_xB); }

@@ -1,0 +1,204 @@
+// cg_links.hip -- the exchange kernel of the direct xGMI path and the box plumbing
+// (see cg_links.hpp for the protocol).
+#include "cg_links.hpp"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "hip_check.hpp"
+
+namespace cgamd
+{
+
+// dst[0..n) = src[0..n) spread over the whole grid; 16-byte accesses when both sides allow it
+__device__ __forceinline__ void grid_copy(float *__restrict__ dst, const float *__restrict__ src, unsigned long long n)
+{
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((((uintptr_t)dst | (uintptr_t)src) % 16) == 0)
+  {
+    const unsigned long long n4 = n >> 2;
+    for (unsigned long long i = t; i < n4; i += step)
+      reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i];
+    for (unsigned long long i = (n4 << 2) + t; i < n; i += step)
+      dst[i] = src[i];
+  }
+  else
+  {
+    for (unsigned long long i = t; i < n; i += step)
+      dst[i] = src[i];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_exchange(const LinkArgs L)
+{
+  __shared__ double sh[8];
+  __shared__ double shv[CG_LINKS_MAX_RANKS];
+  __shared__ int sh_last, sh_bad;
+  if (!L.force && L.st->activeB == 0)
+    return;
+  LinkCtl *ctl = L.ctl;
+  const int kind = L.kind, tid = threadIdx.x;
+  const unsigned long long seq = ctl->seq[kind] + 1;
+  const int par = (int)(seq & 1);
+  const bool planes = L.r_first != nullptr;
+  const bool has_lo = L.rank > 0, has_hi = L.rank + 1 < L.world;
+
+  // ---- push this rank's boundary planes of r into the neighbours' staging areas ------------
+  if (planes)
+  {
+    if (has_lo)
+      grid_copy(links_staging(L.box[L.rank - 1], par, LINK_FROM_HI, L.plane_pad), L.r_first, L.plane);
+    if (has_hi)
+      grid_copy(links_staging(L.box[L.rank + 1], par, LINK_FROM_LO, L.plane_pad), L.r_last, L.plane);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0)
+  {
+    const unsigned t = __hip_atomic_fetch_add(&ctl->ticket[kind], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    sh_last = (t == gridDim.x - 1);
+    sh_bad = 0;
+  }
+  __syncthreads();
+
+  if (sh_last)
+  {
+    // ---- the last workgroup to arrive publishes this rank's sum and collects everyone's -----
+    const double local = block_read_sum(L.part, L.nparts, sh);
+    const bool poisoned = ctl->error != 0;
+    if (tid < L.world)
+    {
+      LinkSlot *s = &L.box[tid]->slot[kind][par][L.rank];
+      const double mine = poisoned ? (double)NAN : local;
+      __hip_atomic_store(&s->value, (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&s->stamp, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      LinkSlot *m = &L.box[L.rank]->slot[kind][par][tid];
+      const long long t0 = wall_clock64();
+      bool ok = true;
+      while (__hip_atomic_load(&m->stamp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq)
+      {
+        if (poisoned || wall_clock64() - t0 > L.budget)
+        {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const unsigned long long bits = __hip_atomic_load(&m->value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      shv[tid] = ok ? __longlong_as_double((long long)bits) : (double)NAN;
+      if (!ok)
+        sh_bad = 1;
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+      double tot = 0;
+      for (int j = 0; j < L.world; j++)
+        tot += shv[j];
+      ctl->sum[kind] = tot;
+      ctl->seq[kind] = seq;
+      ctl->ticket[kind] = 0;
+      if (sh_bad)
+        ctl->error = 1;
+      if (planes && gridDim.x > 1)
+        __hip_atomic_store(&ctl->go[kind], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  else
+  {
+    if (!planes)
+      return;
+    if (tid == 0)
+    {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(&ctl->go[kind], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq)
+      {
+        if (wall_clock64() - t0 > 2 * L.budget)
+          break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+  if (!planes)
+    return;
+  // ---- neighbours' planes: staging -> ghost planes of r ------------------------------------
+  __syncthreads();
+  __threadfence_system();
+  if (has_lo)
+    grid_copy(L.ghost_lo, links_staging(L.box[L.rank], par, LINK_FROM_LO, L.plane_pad), L.plane);
+  if (has_hi)
+    grid_copy(L.ghost_hi, links_staging(L.box[L.rank], par, LINK_FROM_HI, L.plane_pad), L.plane);
+}
+
+// ---- boxes -----------------------------------------------------------------------------------
+
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handles travel as 64 bytes");
+
+int links_alloc(size_t bytes, void **box)
+{
+  *box = nullptr;
+  // memory that no cache of this GPU keeps: remote ranks write it while local kernels poll it
+  hipError_t e = hipExtMallocWithFlags(box, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess)
+  {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(box, bytes, hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess)
+  {
+    (void)hipGetLastError();
+    *box = nullptr;
+    return (int)e;
+  }
+  e = hipMemset(*box, 0, bytes);
+  if (e == hipSuccess)
+    e = hipDeviceSynchronize();
+  if (e != hipSuccess)
+  {
+    (void)hipGetLastError();
+    (void)hipFree(*box);
+    *box = nullptr;
+  }
+  return (int)e;
+}
+
+int links_free(void *box)
+{
+  const hipError_t e = hipFree(box);
+  (void)hipGetLastError();
+  return (int)e;
+}
+
+int links_export(void *box, unsigned char handle[64])
+{
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, box);
+  (void)hipGetLastError();
+  if (e == hipSuccess)
+    memcpy(handle, &h, 64);
+  return (int)e;
+}
+
+int links_open(const unsigned char handle[64], void **box)
+{
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, 64);
+  *box = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(box, h, hipIpcMemLazyEnablePeerAccess);
+  (void)hipGetLastError();
+  return (int)e;
+}
+
+int links_close(void *box)
+{
+  const hipError_t e = hipIpcCloseMemHandle(box);
+  (void)hipGetLastError();
+  return (int)e;
+}
+
+} // namespace cgamd

@@ -317,6 +317,8 @@ Solver::~Solver()
   (void)hipFree(partA_own_);
   (void)hipFree(partB_own_);
   (void)hipFree(st_);
+  if (link_ctl_)
+    (void)hipFree(link_ctl_);
   (void)hipHostFree(st_host_);
   if (own_stream_)
     (void)hipStreamDestroy(stream_);
@@ -619,7 +621,99 @@ void Solver::add_iterations(int n)
 void Solver::begin(const float *b_dev, float *x_dev, double rel, int lagged)
 {
   begin_local(b_dev, x_dev);
+  if (linked_)
+    launch_exchange(1, true);
   init_state(rel, lagged, 0);
+}
+
+void Solver::bind_links(int rank, int world, void *const *boxes)
+{
+  if (world == 0)
+  {
+    // back to the caller-driven step interface with the solver's own partials
+    CHECK(hipStreamSynchronize(stream_));
+    linked_ = false;
+    partA_ = partA_own_;
+    partB_ = partB_own_;
+    bind_sums(nullptr, 0, nullptr, 0);
+    return;
+  }
+  CG_REQUIRE(world >= 1 && world <= CG_LINKS_MAX_RANKS, "direct links support 1..64 ranks");
+  CG_REQUIRE(rank >= 0 && rank < world, "rank out of range");
+  CG_REQUIRE((desc_.has_lo != 0) == (rank > 0) && (desc_.has_hi != 0) == (rank + 1 < world),
+             "has_lo / has_hi of the solver do not match its rank");
+  memset(&links_, 0, sizeof(links_));
+  for (int j = 0; j < world; j++)
+  {
+    CG_REQUIRE(boxes[j] != nullptr, "null box");
+    links_.box[j] = static_cast<LinkBox *>(boxes[j]);
+  }
+  if (!link_ctl_)
+    CHECK(hipMalloc((void **)&link_ctl_, sizeof(LinkCtl)));
+  CHECK(hipMemsetAsync(link_ctl_, 0, sizeof(LinkCtl), stream_));
+  links_.ctl = link_ctl_;
+  links_.st = st_;
+  links_.rank = rank;
+  links_.world = world;
+  links_.plane = plane_;
+  links_.plane_pad = links_plane_pad(plane_);
+  links_.budget = (long long)std::max(1, env_int("CG_LINKS_TIMEOUT_MS", 10000)) * 100000ll; // 100 MHz ticks
+  partA_ = partA_own_;
+  partB_ = partB_own_;
+  bind_sums(&link_ctl_->sum[0], 1, &link_ctl_->sum[1], 1);
+  linked_ = true;
+}
+
+void Solver::launch_exchange(int kind, bool force)
+{
+  CG_REQUIRE(linked_, "no boxes bound");
+  LinkArgs L = links_;
+  L.kind = kind;
+  L.force = force ? 1 : 0;
+  L.part = kind ? partB_ : partA_;
+  L.nparts = grid_;
+  int blocks = 1;
+  if (kind == 1 && (desc_.has_lo || desc_.has_hi))
+  {
+    L.r_first = r_;
+    L.r_last = r_ + N_ - plane_;
+    L.ghost_lo = r_ - plane_;
+    L.ghost_hi = r_ + N_;
+    // one workgroup per 64 KiB of plane, at most 64: enough to fill the two links it writes to
+    const size_t want = (plane_ * sizeof(float) + 65535) / 65536;
+    blocks = (int)std::max<size_t>(1, std::min<size_t>(want, 64));
+    blocks = std::max(1, std::min(env_int("CG_LINKS_BLOCKS", blocks), 256));
+  }
+  hipLaunchKernelGGL(k_exchange, dim3(blocks), dim3(256), 0, stream_, L);
+  CHECK(hipGetLastError());
+}
+
+int Solver::links_error()
+{
+  if (!linked_)
+    return 0;
+  int e = 0;
+  CHECK(hipMemcpyAsync(&e, &link_ctl_->error, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  CHECK(hipStreamSynchronize(stream_));
+  return e;
+}
+
+void Solver::links_times(float *ms_xA, float *ms_xB) const
+{
+  if (ms_xA)
+    *ms_xA = ms_xA_;
+  if (ms_xB)
+    *ms_xB = ms_xB_;
+}
+
+void Solver::launch_iteration()
+{
+  launch_A();
+  if (linked_)
+    launch_exchange(0, false);
+  launch_B();
+  if (linked_)
+    launch_exchange(1, false);
 }
 
 void Solver::iterate(int n, bool use_graph)
@@ -631,10 +725,7 @@ void Solver::iterate(int n, bool use_graph)
   if (!use_graph)
   {
     for (int i = 0; i < n; i++)
-    {
-      launch_A();
-      launch_B();
-    }
+      launch_iteration();
     return;
   }
   if (!graph_ || graph_iters_ != chunk)
@@ -644,10 +735,7 @@ void Solver::iterate(int n, bool use_graph)
     hipGraph_t g;
     CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < chunk; i++)
-    {
-      launch_A();
-      launch_B();
-    }
+      launch_iteration();
     CHECK(hipStreamEndCapture(stream_, &g));
     CHECK(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
     CHECK(hipGraphDestroy(g));
@@ -702,34 +790,41 @@ int Solver::finish(float *residue, float *hist, int hist_len)
 
 void Solver::time_kernels(int n, float *ms_A, float *ms_B)
 {
-  std::vector<hipEvent_t> ev(3 * (size_t)n);
+  std::vector<hipEvent_t> ev(5 * (size_t)n);
   for (auto &e : ev)
     CHECK(hipEventCreate(&e));
   add_iterations(n);
   for (int i = 0; i < n; i++)
   {
-    CHECK(hipEventRecord(ev[3 * i], stream_));
+    CHECK(hipEventRecord(ev[5 * i], stream_));
     launch_A();
-    CHECK(hipEventRecord(ev[3 * i + 1], stream_));
+    CHECK(hipEventRecord(ev[5 * i + 1], stream_));
+    if (linked_)
+      launch_exchange(0, false);
+    CHECK(hipEventRecord(ev[5 * i + 2], stream_));
     launch_B();
-    CHECK(hipEventRecord(ev[3 * i + 2], stream_));
+    CHECK(hipEventRecord(ev[5 * i + 3], stream_));
+    if (linked_)
+      launch_exchange(1, false);
+    CHECK(hipEventRecord(ev[5 * i + 4], stream_));
   }
   CHECK(hipStreamSynchronize(stream_));
-  double ta = 0, tb = 0;
+  double t[4] = {0, 0, 0, 0};
   for (int i = 0; i < n; i++)
-  {
-    float m;
-    CHECK(hipEventElapsedTime(&m, ev[3 * i], ev[3 * i + 1]));
-    ta += m;
-    CHECK(hipEventElapsedTime(&m, ev[3 * i + 1], ev[3 * i + 2]));
-    tb += m;
-  }
+    for (int j = 0; j < 4; j++)
+    {
+      float m;
+      CHECK(hipEventElapsedTime(&m, ev[5 * i + j], ev[5 * i + j + 1]));
+      t[j] += m;
+    }
   for (auto &e : ev)
     CHECK(hipEventDestroy(e));
   if (ms_A)
-    *ms_A = (float)(ta / n);
+    *ms_A = (float)(t[0] / n);
   if (ms_B)
-    *ms_B = (float)(tb / n);
+    *ms_B = (float)(t[2] / n);
+  ms_xA_ = (float)(t[1] / n);
+  ms_xB_ = (float)(t[3] / n);
 }
 
 // ---- free functions ---------------------------------------------------------------------

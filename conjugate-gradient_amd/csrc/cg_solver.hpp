@@ -7,6 +7,7 @@
 #include <stddef.h>
 
 #include "cg_device.hpp"
+#include "cg_links.hpp"
 #include "cg_morton.hpp"
 #include "cg_planes.hpp"
 
@@ -85,8 +86,18 @@ public:
   // per-kernel device time over n iterations, HIP events on stream(); plain launches
   void time_kernels(int n, float *ms_A, float *ms_B);
 
+  // ---- direct xGMI path (cg_links.hpp): with boxes bound, begin / iterate / finish above run
+  // the multi-rank solve by themselves (an exchange launch after every kernel A and B) -------
+  // boxes[0..world): every rank's box as mapped in this process, boxes[rank] this rank's own
+  void bind_links(int rank, int world, void *const *boxes);
+  bool linked() const { return linked_; }
+  void launch_exchange(int kind, bool force); // kind 0: p.Ap; 1: r.r and r's boundary planes
+  int links_error();                          // synchronises; 1 if a wait ever ran out of time
+  void links_times(float *ms_xA, float *ms_xB) const; // exchange launches, from the last time_kernels
+
 private:
   void build_geometry();
+  void launch_iteration(); // A, B and, with boxes bound, the exchange after each
   void launch_mode(int mode, bool ghost, const VecArgs &a);
   VecArgs args() const;
 
@@ -111,6 +122,10 @@ private:
   int planes_r_ = 4;
   ScalarGeom sg_{};
   int grid_ = 1, block_ = 256;
+  bool linked_ = false;
+  LinkArgs links_{};
+  LinkCtl *link_ctl_ = nullptr;
+  float ms_xA_ = 0, ms_xB_ = 0;
   hipGraphExec_t graph_ = nullptr;
   int graph_iters_ = 0;
   float *graph_x_ = nullptr;

@@ -9,12 +9,18 @@ iteration the ranks exchange
     (a few KiB of device doubles, no separate reduction launch); alpha and beta are then derived
     on every rank's device from identical bits, so all ranks take the same path.
 
+With `enable_links()` the ranks of one node drop the collectives and write the same data
+straight into each other's HBM over xGMI from a small kernel after A and after B (see
+csrc/cg_links.hpp); the whole multi-rank iteration is then four launches replayed from a
+hipGraph.  RCCL stays the portable default and the fallback.
+
 Everything is enqueued asynchronously on the current stream; the host never waits inside
 the loop.  The compute steps are the HIP library's kernels (binding.Solver); a different
 `make_ops` can be injected so that the exchange logic can be exercised on CPU tensors with
 the gloo backend.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -54,6 +60,10 @@ class HipSlabOps:
         self.stream.wait_stream(torch.cuda.default_stream(self.device))
         self.solver.begin_local(b.data_ptr(), x.data_ptr())
 
+    def begin_linked(self, b, x, rel, lagged):
+        self.stream.wait_stream(torch.cuda.default_stream(self.device))
+        self.solver.begin(b.data_ptr(), x.data_ptr(), rel, lagged)
+
     def sum_tensor(self, which):
         """The tensor whose element-wise sum over ranks the next kernel consumes."""
         return self.parts[which, :self.nparts]
@@ -90,6 +100,8 @@ class SlabCG:
         self.extents = [int(e) for e in extents]
         if len(self.extents) < 2 and self.world > 1:
             raise ValueError("slab decomposition needs d >= 2")
+        self.links = False
+        self.links_reason = ""
         self.has_lo = self.rank > 0
         self.has_hi = self.rank < self.world - 1
         self.N = 1
@@ -163,6 +175,70 @@ class SlabCG:
         for dst, buf in recvs:
             dst.copy_(buf)
 
+    # -- direct xGMI path ---------------------------------------------------------------
+    def enable_links(self):
+        """Map every rank's box into this process and bind them to the solver.  Collective: all
+        ranks call it; returns True on all ranks or False on all ranks (then nothing changed)."""
+        if self.links:
+            return True
+        lib, solver = self.ops.lib, self.ops.solver
+        ok, handle = 1, b""
+        try:
+            self._box = lib.links_alloc(solver.box_bytes())
+            handle = lib.links_export(self._box)
+        except Exception as e:  # noqa: BLE001 -- any failure means "use the collectives"
+            ok, self.links_reason = 0, repr(e)
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, (ok, os.getpid(), handle), group=self.group)
+        boxes, self._opened = [], []
+        if all(g[0] for g in gathered):
+            try:
+                for j, (_, pid, h) in enumerate(gathered):
+                    if j == self.rank:
+                        boxes.append(self._box)
+                    else:
+                        # an IPC handle cannot be opened by the process that made it
+                        p = lib.links_open(h)
+                        self._opened.append(p)
+                        boxes.append(p)
+            except Exception as e:  # noqa: BLE001
+                ok, self.links_reason = 0, repr(e)
+        else:
+            ok = 0
+        if not self._all_agree(ok):
+            self._release_links()
+            return False
+        solver.bind_links(self.rank, boxes)
+        self.links = True
+        return True
+
+    def disable_links(self):
+        """Back to collectives (collective call)."""
+        if not self.links:
+            return
+        self.ops.solver.bind_links(self.rank, [])   # waits for this rank's stream
+        self.ops.solver.bind_partials(self.ops.parts[0].data_ptr(), self.ops.parts[1].data_ptr())
+        self.links = False
+        dist.barrier(group=self.group)                # nobody writes into a box any more
+        self._release_links()
+
+    def links_error(self):
+        return self.ops.solver.links_error() if self.links else 0
+
+    def _all_agree(self, ok):
+        votes = [None] * self.world
+        dist.all_gather_object(votes, int(ok), group=self.group)
+        return all(votes)
+
+    def _release_links(self):
+        lib = self.ops.lib
+        for p in getattr(self, "_opened", []):
+            lib.links_close(p)
+        self._opened = []
+        if getattr(self, "_box", None):
+            lib.links_free(self._box)
+            self._box = None
+
     # -- solve --------------------------------------------------------------------------
     def _ctx(self):
         return self.ops.stream_ctx() if hasattr(self.ops, "stream_ctx") else contextlib.nullcontext()
@@ -170,6 +246,9 @@ class SlabCG:
     def begin(self, b, x, rel=1e-6, lagged=1):
         """b, x: this rank's slab (N floats each).  r = b, p = 0, global r.r, ghost planes of r."""
         with self._ctx():
+            if self.links:
+                self.ops.begin_linked(b, x, rel, lagged)
+                return
             self.ops.begin_local(b, x)
             self.allreduce(1)
             self.ops.init_state(rel, lagged, 0)
@@ -177,6 +256,9 @@ class SlabCG:
 
     def iterate(self, n):
         with self._ctx():
+            if self.links:
+                self.ops.solver.iterate(n, True)
+                return
             self.ops.add_iterations(n)
             for _ in range(n):
                 self.ops.kernel_A()
@@ -186,7 +268,10 @@ class SlabCG:
                 self.exchange_r()
 
     def finish(self, hist_len=0):
-        return self.ops.finish(hist_len)
+        out = self.ops.finish(hist_len)
+        if self.links and self.ops.solver.links_error():
+            raise RuntimeError("direct xGMI exchange timed out waiting for another rank; the result is invalid")
+        return out
 
     def sync(self):
         self.ops.sync()

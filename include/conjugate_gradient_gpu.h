@@ -147,6 +147,32 @@ extern "C"
   float *cg_solver_r(cg_solver *s);              /* first owned element of r */
   float *cg_solver_p(cg_solver *s, int which);   /* first owned element of p0 / p1 */
 
+  /* --- direct xGMI path: slab neighbours write into each other's HBM, no collective library ---
+   * (no counterpart in the reference, which is single-GPU).  Every rank allocates a box,
+   * passes its handle to the other ranks of the node (any channel: the 64 bytes are plain
+   * data), opens theirs and binds all `world` boxes to its solver.  From then on
+   * cg_solver_begin / cg_solver_iterate / cg_solver_finish run the multi-rank solve by
+   * themselves: after kernel A and kernel B a small launch publishes this rank's dot product
+   * (and, after B, r's boundary planes) into the other ranks' boxes and waits for theirs, so
+   * an iteration is four launches, replayed from a hipGraph, and no host work.  The solver's
+   * has_lo / has_hi must match its rank.  cg_links_* return a hipError_t value, 0 = success
+   * (they never terminate the process, so a caller can fall back to collectives). */
+  size_t cg_links_box_bytes(const cg_solver_desc *desc);
+  int cg_links_alloc(size_t bytes, void **box);            /* device memory no cache keeps, zeroed */
+  int cg_links_free(void *box);
+  int cg_links_export(void *box, unsigned char *handle64); /* for the other processes of the node */
+  int cg_links_open(const unsigned char *handle64, void **box);
+  int cg_links_close(void *box);
+  /* boxes[0..world): every rank's box as mapped in this process; boxes[rank] is this rank's own.
+   * world = 0 unbinds (waits for the solver's stream first). */
+  void cg_solver_bind_links(cg_solver *s, int rank, int world, void *const *boxes);
+  void cg_solver_exchange(cg_solver *s, int which, int force); /* step interface: enqueue one exchange */
+  /* 1 if a wait for another rank ever ran out of time (CG_LINKS_TIMEOUT_MS, default 10 s): the
+   * sums were then poisoned with NaN, every rank stopped, and the result is invalid.  Synchronises. */
+  int cg_solver_links_error(cg_solver *s);
+  /* average device milliseconds of the two exchange launches during the last cg_solver_time_kernels */
+  void cg_solver_links_times(cg_solver *s, float *ms_xA, float *ms_xB);
+
 #ifdef __cplusplus
 }
 #endif

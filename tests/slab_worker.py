@@ -1,8 +1,9 @@
-"""Worker for the multi-process slab tests: python slab_worker.py <out.npz> <L> <d> <iters> [hip].
+"""Worker for the multi-process slab tests: python slab_worker.py <out.npz> <L> <d> <iters> [hip|links].
 Reads RANK / WORLD_SIZE / MASTER_* from the environment (gloo).  Without `hip` the per-slab
-compute is the CPU stand-in; with it every rank runs the HIP kernels on cuda:0 (the ranks
+compute is the CPU stand-in; with `hip` every rank runs the HIP kernels on cuda:0 (the ranks
 share the one GPU, the exchange is staged through host memory because RCCL refuses two
-ranks on one device)."""
+ranks on one device); with `links` the ranks exchange through each other's device memory
+(IPC-mapped boxes) and gloo only carries the handles."""
 import os
 import sys
 
@@ -19,7 +20,8 @@ from fake_slab_ops import FakeSlabOps  # noqa: E402
 
 def main():
     out, L, d, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    hip = len(sys.argv) > 5 and sys.argv[5] == "hip"
+    mode = sys.argv[5] if len(sys.argv) > 5 else "cpu"      # cpu | hip | links
+    hip = mode in ("hip", "links")
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg = load_package()
@@ -40,6 +42,8 @@ def main():
         torch.cuda.set_device(dev)
         b_loc, x_loc = b_loc.to(dev), x_loc.to(dev)
         s = SlabCG(pkg.load_library(), ext, device=dev)
+        if mode == "links":
+            assert s.enable_links(), s.links_reason
     else:
         s = SlabCG(None, ext, make_ops=lambda e, lo, hi: FakeSlabOps(e, lo, hi))
     s.begin(b_loc, x_loc, 1e-6, 1)
