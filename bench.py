@@ -7,7 +7,9 @@
 A step is one CG iteration (kernel A + kernel B) over the whole grid.  Workload at every N:
 each GPU owns an 8192 x 8192 float slab (2^26 points, config "2D Laplace 8192^2 float CG");
 with N > 1 the slabs stack along axis 1 into an 8192 x (8192 N) grid (weak scaling) with one
-halo row of r and two scalar all-reduces per iteration over RCCL.  Synthetic data: b = u01
+halo row of r each way and two dot-product exchanges per iteration: written straight into the
+peers' HBM over xGMI when every rank can map every other rank's box and a three-iteration
+self-check reproduces the collectives' residuals, otherwise over RCCL (config.comm says which).  Synthetic data: b = u01
 (counter-based generator, seed 1234), x0 = 0; float CG cannot converge on this grid within
 any practical count, so every step does full work (the stop tolerance is set to 0).
 
@@ -40,6 +42,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-slab", action="store_true", help="run the multi-rank driver even with one rank")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal: host-staged)")
+    ap.add_argument("--comm", default="auto", help="multi-rank exchange: auto (direct xGMI boxes if they pass a "
+                    "self-check, else collectives) | links | collectives")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -218,18 +222,74 @@ def main():
     else:
         from conjugate_gradient_amd.slab import SlabCG
         s = SlabCG(lib, ext, rank=rank, world=world, device=device)
-        s.begin(b, x, 0.0, 1)
-        s.iterate(args.warmup)
-        s.sync()
-        barrier()
-        t0 = time.perf_counter()
-        s.iterate(args.steps)
-        s.sync()
-        barrier()
-        dt = time.perf_counter() - t0
-        done, res, _ = s.finish()
-        assert done == args.warmup + args.steps, (done, args.warmup, args.steps)
+        comm, comm_note = "collectives", ""
+        if args.comm in ("auto", "links"):
+            # three iterations over the collectives, then the same three over the boxes: the direct
+            # path is only used if every rank mapped every box and reproduces the residual history
+            s.begin(b, x, 0.0, 1)
+            s.iterate(3)
+            _, _, hist_c = s.finish(hist_len=3)
+            if s.enable_links():
+                ok = 1
+                try:
+                    x.zero_()
+                    s.begin(b, x, 0.0, 1)
+                    s.iterate(3)
+                    _, _, hist_l = s.finish(hist_len=3)
+                    ok = int(len(hist_l) == 3 and all(abs(a - c) <= 1e-4 * abs(c) for a, c in zip(hist_l, hist_c)))
+                    if not ok:
+                        comm_note = f"self-check mismatch {hist_l} vs {hist_c}"
+                except RuntimeError as e:
+                    ok, comm_note = 0, str(e)
+                if s._all_agree(ok):
+                    comm = "xgmi-links"
+                else:
+                    s.disable_links()
+            else:
+                comm_note = s.links_reason
+            if args.comm == "links" and comm != "xgmi-links":
+                raise SystemExit(f"direct links unavailable: {comm_note}")
+            x.zero_()
+        def timed():
+            x.zero_()
+            barrier()
+            s.begin(b, x, 0.0, 1)
+            s.iterate(args.warmup)
+            s.sync()
+            barrier()
+            t0 = time.perf_counter()
+            s.iterate(args.steps)
+            s.sync()
+            barrier()
+            dt = time.perf_counter() - t0
+            done, res, _ = s.finish()
+            if done != args.warmup + args.steps:
+                raise RuntimeError(f"{done} iterations ran instead of {args.warmup + args.steps}")
+            return dt, res
+
+        ok = 1
+        try:
+            dt, res = timed()
+        except RuntimeError as e:
+            if comm != "xgmi-links":
+                raise
+            ok, comm_note = 0, "timed run over the boxes failed: " + str(e)
+        if comm == "xgmi-links" and not s._all_agree(ok):
+            # a rank lost the direct path under load: everyone goes back to the collectives
+            s.disable_links()
+            comm = "collectives"
+            dt, res = timed()
         parallelism = f"slab{world}"
+        if comm == "xgmi-links":
+            with s._ctx():
+                msA, msB = s.ops.solver.time_kernels(max(10, min(50, args.steps)))
+                s.sync()
+            xA, xB = s.ops.solver.links_times()
+            gB = BYTES_B * N / (msB * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "MODE_B", "achieved": round(gB, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(gB / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes": BYTES_B * N,
+                    "ms_per_launch": round(msB, 5), "other_kernel": {"ms_per_launch": round(msA, 5)},
+                    "exchange_ms": {"after_A": round(xA, 5), "after_B": round(xB, 5)}, "rank": 0}
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -248,6 +308,7 @@ def main():
             "config": {"workload": args.workload, "local_extents": ext, "index_mode": mode,
                        "points_per_gpu": N, "parallelism": parallelism, "graph": not args.no_graph,
                        "backend": args.backend if world > 1 else None,
+                       "comm": (comm + (f" ({comm_note})" if comm_note else "")) if parallelism != "single" else None,
                        "rhs": "u01 seed 1234+rank", "x0": 0},
             "iterations_per_sec_global": round(its, 3),
             "hbm_algorithmic_GBps": round(BYTES_ITER * N * world * its / 1e9, 1),
