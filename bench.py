@@ -236,12 +236,15 @@ def main():
                     s.begin(b, x, 0.0, 1)
                     s.iterate(3)
                     _, _, hist_l = s.finish(hist_len=3)
-                    ok = int(len(hist_l) == 3 and all(abs(a - c) <= 1e-4 * abs(c) for a, c in zip(hist_l, hist_c)))
+                    ok = int(len(hist_l) == 3 and all(abs(a - c) <= 1e-5 * abs(c) for a, c in zip(hist_l, hist_c)))
                     if not ok:
                         comm_note = f"self-check mismatch {hist_l} vs {hist_c}"
                 except RuntimeError as e:
                     ok, comm_note = 0, str(e)
-                if s._all_agree(ok):
+                ok = s._all_agree(ok)
+                if ok and not s._all_agree(s.ghosts_match_neighbours()):
+                    ok, comm_note = False, "self-check: ghost planes differ from the neighbours' boundary planes"
+                if ok:
                     comm = "xgmi-links"
                 else:
                     s.disable_links()

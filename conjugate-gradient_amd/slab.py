@@ -225,6 +225,37 @@ class SlabCG:
     def links_error(self):
         return self.ops.solver.links_error() if self.links else 0
 
+    def ghosts_match_neighbours(self):
+        """After finish(): fetch the neighbours' boundary planes of r once more through
+        torch.distributed and compare them bit for bit with this rank's ghost planes (what the
+        last exchange of the solve must have delivered).  Collective; returns this rank's verdict."""
+        self.sync()
+        if self.world == 1:
+            return True
+        staged = self._host_staged(self.r_first)
+        dev = "cpu" if staged else self.r_first.device
+        lo = torch.empty(self.r_ghost_lo.shape, dtype=self.r_ghost_lo.dtype, device=dev)
+        hi = torch.empty(self.r_ghost_hi.shape, dtype=self.r_ghost_hi.dtype, device=dev)
+        first = self.r_first.cpu() if staged else self.r_first.clone()
+        last = self.r_last.cpu() if staged else self.r_last.clone()
+        ops = []
+        if self.has_lo:
+            ops.append(dist.P2POp(dist.isend, first, self._global_rank(self.rank - 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, lo, self._global_rank(self.rank - 1), self.group))
+        if self.has_hi:
+            ops.append(dist.P2POp(dist.isend, last, self._global_rank(self.rank + 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, hi, self._global_rank(self.rank + 1), self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if not staged:
+            torch.cuda.synchronize(self.r_first.device)
+        ok = True
+        if self.has_lo:
+            ok = ok and torch.equal(lo.to(self.r_ghost_lo.device), self.r_ghost_lo)
+        if self.has_hi:
+            ok = ok and torch.equal(hi.to(self.r_ghost_hi.device), self.r_ghost_hi)
+        return ok
+
     def _all_agree(self, ok):
         votes = [None] * self.world
         dist.all_gather_object(votes, int(ok), group=self.group)

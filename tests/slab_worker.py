@@ -49,6 +49,8 @@ def main():
     s.begin(b_loc, x_loc, 1e-6, 1)
     s.iterate(iters)
     n, res, hist = s.finish(hist_len=iters)
+    if hip:
+        assert s.ghosts_match_neighbours()
     x_loc = x_loc.cpu()
     gathered = [torch.zeros(n_loc, dtype=torch.float32) for _ in range(world)]
     dist.all_gather(gathered, x_loc)
