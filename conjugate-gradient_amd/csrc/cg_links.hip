@@ -38,11 +38,18 @@ __global__ void __launch_bounds__(256) k_exchange(const LinkArgs L)
   __shared__ double sh[8];
   __shared__ double shv[CG_LINKS_MAX_RANKS];
   __shared__ int sh_last, sh_bad;
-  if (!L.force && L.st->activeB == 0)
-    return;
   LinkCtl *ctl = L.ctl;
   const int kind = L.kind, tid = threadIdx.x;
+  // independent loads first, so that their latencies overlap
+  const int active = L.force | L.st->activeB;
   const unsigned long long seq = ctl->seq[kind] + 1;
+  const bool poisoned = ctl->error != 0;
+  const bool single = gridDim.x == 1;
+  double local = 0;
+  if (single)
+    local = block_read_sum(L.part, L.nparts, sh);
+  if (!active)
+    return;
   const int par = (int)(seq & 1);
   const bool planes = L.r_first != nullptr;
   const bool has_lo = L.rank > 0, has_hi = L.rank + 1 < L.world;
@@ -54,34 +61,48 @@ __global__ void __launch_bounds__(256) k_exchange(const LinkArgs L)
       grid_copy(links_staging(L.box[L.rank - 1], par, LINK_FROM_HI, L.plane_pad), L.r_first, L.plane);
     if (has_hi)
       grid_copy(links_staging(L.box[L.rank + 1], par, LINK_FROM_LO, L.plane_pad), L.r_last, L.plane);
+    __threadfence_system(); // the planes are on their way before any stamp is
   }
-  __threadfence_system();
-  __syncthreads();
-  if (tid == 0)
+  bool last = true;
+  if (!single)
   {
-    const unsigned t = __hip_atomic_fetch_add(&ctl->ticket[kind], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    sh_last = (t == gridDim.x - 1);
-    sh_bad = 0;
+    __syncthreads();
+    if (tid == 0)
+    {
+      const unsigned t = __hip_atomic_fetch_add(&ctl->ticket[kind], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      sh_last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    last = sh_last != 0;
+    if (last)
+      local = block_read_sum(L.part, L.nparts, sh);
   }
-  __syncthreads();
+  else if (planes)
+    __syncthreads(); // every wave's plane stores are fenced before wave 0 stamps
 
-  if (sh_last)
+  if (last)
   {
     // ---- the last workgroup to arrive publishes this rank's sum and collects everyone's -----
-    const double local = block_read_sum(L.part, L.nparts, sh);
-    const bool poisoned = ctl->error != 0;
+    if (tid == 0)
+      sh_bad = 0;
+    __syncthreads();
     if (tid < L.world)
     {
+      const unsigned long long tag = (seq & 0xffffffffull) << 32;
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(poisoned ? (double)NAN : local);
       LinkSlot *s = &L.box[tid]->slot[kind][par][L.rank];
-      const double mine = poisoned ? (double)NAN : local;
-      __hip_atomic_store(&s->value, (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(&s->stamp, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&s->w[0], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&s->w[1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       LinkSlot *m = &L.box[L.rank]->slot[kind][par][tid];
       const long long t0 = wall_clock64();
       bool ok = true;
-      while (__hip_atomic_load(&m->stamp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq)
+      unsigned long long w0, w1;
+      for (;;)
       {
+        w0 = __hip_atomic_load(&m->w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        w1 = __hip_atomic_load(&m->w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((w0 & ~0xffffffffull) == tag && (w1 & ~0xffffffffull) == tag)
+          break;
         if (poisoned || wall_clock64() - t0 > L.budget)
         {
           ok = false;
@@ -89,8 +110,8 @@ __global__ void __launch_bounds__(256) k_exchange(const LinkArgs L)
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      const unsigned long long bits = __hip_atomic_load(&m->value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      shv[tid] = ok ? __longlong_as_double((long long)bits) : (double)NAN;
+      const unsigned long long got = (w0 & 0xffffffffull) | (w1 << 32);
+      shv[tid] = ok ? __longlong_as_double((long long)got) : (double)NAN;
       if (!ok)
         sh_bad = 1;
     }
@@ -102,11 +123,14 @@ __global__ void __launch_bounds__(256) k_exchange(const LinkArgs L)
         tot += shv[j];
       ctl->sum[kind] = tot;
       ctl->seq[kind] = seq;
-      ctl->ticket[kind] = 0;
       if (sh_bad)
         ctl->error = 1;
-      if (planes && gridDim.x > 1)
-        __hip_atomic_store(&ctl->go[kind], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (!single)
+      {
+        ctl->ticket[kind] = 0;
+        if (planes)
+          __hip_atomic_store(&ctl->go[kind], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   else

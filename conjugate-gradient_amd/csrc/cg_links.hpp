@@ -5,8 +5,8 @@
 //
 //   * slots: one (value, stamp) pair per kind of dot product, stamp parity and source rank.
 //     After kernel A or B a rank sums its own per-workgroup partials in the usual fixed order
-//     and stores that one double, then the stamp, into the slot [kind][parity][own rank] of
-//     EVERY rank's box; it then waits until all `world` stamps of its own box carry the
+//     and stores that one double, tagged with the stamp, into the slot [kind][parity][own rank]
+//     of EVERY rank's box; it then waits until all `world` stamps of its own box carry the
 //     current sequence number and adds the values in rank order.  All ranks add the same
 //     doubles in the same order, so alpha, beta and the stop test agree bit for bit.
 //   * staging planes: with the r.r exchange a rank also stores its first / last owned
@@ -33,10 +33,13 @@ namespace cgamd
 
 constexpr int CG_LINKS_MAX_RANKS = 64;
 
+// A slot is two 8-byte words, each carrying half of the double next to the low 32 bits of the
+// stamp.  An aligned 8-byte store arrives whole, so a reader that finds the expected stamp in
+// both words has the value: the writer needs no fence between value and flag, and the reader
+// needs one load round trip per poll.
 struct LinkSlot
 {
-  unsigned long long value; // bits of a double
-  unsigned long long stamp;
+  unsigned long long w[2]; // w[i] = (stamp32 << 32) | (i ? hi32 : lo32) of the double's bits
 };
 
 // shared part of a box; the staging planes follow at byte offset CG_LINKS_HEADER:
