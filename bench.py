@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="2d-8192", help="2d-8192 | 3d-1024x128 | 3d-512 | 4d-128-morton | LxLx..[:mode]")
+    ap.add_argument("--workload", default="2d-8192", help="2d-8192 | 3d-1024x128 | 3d-512 | 3d-1024 | 4d-128-morton | LxLx..[:mode]")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-slab", action="store_true", help="run the multi-rank driver even with one rank")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal: host-staged)")
@@ -57,6 +57,8 @@ def workload_extents(name):
         ext = [1024, 1024, 128]
     elif name == "3d-512":
         ext = [512, 512, 512]
+    elif name == "3d-1024":
+        ext = [1024, 1024, 1024]
     elif name == "4d-128-morton":
         ext, mode = [128] * 4, 2
     else:
