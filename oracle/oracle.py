@@ -223,8 +223,9 @@ class Oracle:
 class Reference:
     """The reference's own CPU code (oracle/_ref).  None-like when not built."""
 
-    def __init__(self):
-        self.lib = _load("_ref/libcg_ref.so")
+    def __init__(self, native=False):
+        """native=True loads the -O3 -march=x86-64-v3 timing build of the same sources."""
+        self.lib = _load("_ref/libcg_ref_opt.so" if native else "_ref/libcg_ref.so")
         self.mlib = _load("_ref/libcg_ref_morton.so")
         if self.lib is not None:
             L = self.lib
