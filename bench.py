@@ -239,19 +239,37 @@ def main():
         from conjugate_gradient_amd.slab import SlabCG
         s = SlabCG(lib, ext, rank=rank, world=world, device=device)
         comm, comm_note = "collectives", ""
-        if args.comm in ("auto", "links"):
-            # three iterations over the collectives, then the same three over the boxes: the direct
-            # path is only used if every rank mapped every box and reproduces the residual history
+
+        def probe(n=30):
+            """A short timed run on the current transport: (seconds for n iterations, max over
+            ranks; residual history of the first three iterations)."""
+            x.zero_()
+            barrier()
             s.begin(b, x, 0.0, 1)
             s.iterate(3)
-            _, _, hist_c = s.finish(hist_len=3)
+            s.sync()
+            barrier()
+            t0 = time.perf_counter()
+            s.iterate(n)
+            s.sync()
+            barrier()
+            dt = time.perf_counter() - t0
+            _, _, hist = s.finish(hist_len=3)
+            times = [None] * world
+            if world > 1:
+                dist.all_gather_object(times, dt)
+            else:
+                times = [dt]
+            return max(times), hist
+
+        if args.comm in ("auto", "links"):
+            # the direct path is used only if every rank mapped every box, the boxes reproduce the
+            # collectives' residual history and ghost planes bit for bit, and it is not slower
+            t_coll, hist_c = probe()
             if s.enable_links():
-                ok = 1
+                ok, t_link = 1, float("inf")
                 try:
-                    x.zero_()
-                    s.begin(b, x, 0.0, 1)
-                    s.iterate(3)
-                    _, _, hist_l = s.finish(hist_len=3)
+                    t_link, hist_l = probe()
                     ok = int(len(hist_l) == 3 and all(abs(a - c) <= 1e-5 * abs(c) for a, c in zip(hist_l, hist_c)))
                     if not ok:
                         comm_note = f"self-check mismatch {hist_l} vs {hist_c}"
@@ -260,8 +278,11 @@ def main():
                 ok = s._all_agree(ok)
                 if ok and not s._all_agree(s.ghosts_match_neighbours()):
                     ok, comm_note = False, "self-check: ghost planes differ from the neighbours' boundary planes"
+                if ok and args.comm == "auto" and t_link > t_coll:
+                    ok, comm_note = False, f"boxes slower than collectives in the probe ({t_link:.4f} s vs {t_coll:.4f} s)"
                 if ok:
                     comm = "xgmi-links"
+                    comm_note = f"probe: {t_link:.4f} s vs {t_coll:.4f} s over collectives for 30 iterations"
                 else:
                     s.disable_links()
             else:
