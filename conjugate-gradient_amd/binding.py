@@ -17,7 +17,7 @@ EXPORTS = [
     "time_cpu_laplace", "add_jl", "laplace_gpu_jl",
     # part 2: additions
     "cg_allocate_field", "cg_free_field", "conjugate_gradient_gpu_ex", "preconditioned_cg_gpu",
-    "cg_laplace_device", "cg_fill_uniform", "cg_u01_host",
+    "cg_laplace_device", "cg_fill_uniform", "cg_u01_host", "cg_strong_scaling_events", "cg_laplace_time_events",
     "cg_solver_buffer_len", "cg_solver_ghost_offset", "cg_solver_plane", "cg_solver_create",
     "cg_solver_destroy", "cg_solver_engine", "cg_solver_blocks", "cg_solver_begin", "cg_solver_iterate",
     "cg_solver_finish", "cg_solver_sync", "cg_solver_time_kernels", "cg_solver_begin_local",
@@ -91,6 +91,10 @@ class Library:
         c.cg_fill_uniform.restype = None
         c.cg_u01_host.argtypes = [u32, C.c_ulonglong]
         c.cg_u01_host.restype = C.c_float
+        c.cg_strong_scaling_events.argtypes = [i32] * 6
+        c.cg_strong_scaling_events.restype = C.c_float
+        c.cg_laplace_time_events.argtypes = [i32] * 4
+        c.cg_laplace_time_events.restype = C.c_float
         dp = C.POINTER(SolverDesc)
         for f in ("cg_solver_buffer_len", "cg_solver_ghost_offset", "cg_solver_plane"):
             getattr(c, f).argtypes = [dp]
@@ -172,6 +176,12 @@ class Library:
         self.c.laplace_gpu_jl(_ptr(ddf), _ptr(u), dx, d, L, N, index_mode, blocks, threads)
 
     # ---- additions -------------------------------------------------------------------
+    def strong_scaling_events(self, nblocks, threads_per_block, N, L, d, reps=5):
+        return self.c.cg_strong_scaling_events(nblocks, threads_per_block, N, L, d, reps)
+
+    def laplace_time_events(self, L, d, index_mode=0, reps=5):
+        return self.c.cg_laplace_time_events(L, d, index_mode, reps)
+
     def conjugate_gradient_gpu_ex(self, b, x, L, d, index_mode=0, maxit=200, rel=1e-6, lagged=1,
                                   verbose=0, hist_len=0):
         """Returns (residue, iterations, history)."""

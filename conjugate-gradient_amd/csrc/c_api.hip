@@ -95,16 +95,19 @@ unsigned long long grid_points(int L, int d)
 // benchmarks) reuse r/p buffers and the captured graph
 struct Cache
 {
-  int L = 0, d = 0, mode = -1, device = -1;
+  int L = 0, d = 0, mode = -1, device = -1, forced = 0;
   std::unique_ptr<Solver> solver;
   Solver &get(int L_, int d_, int mode_)
   {
     const int m = mode_ == 2 ? 2 : 0;
     int dev = 0;
     CHECK(hipGetDevice(&dev));
-    if (!solver || L != L_ || d != d_ || mode != m || device != dev)
+    const char *e = getenv("CG_ENGINE"); // part of the key: it changes which engine a new solver picks
+    const int f = (e && *e) ? atoi(e) : 0;
+    if (!solver || L != L_ || d != d_ || mode != m || device != dev || forced != f)
     {
       device = dev;
+      forced = f;
       solver.reset();
       SolverDesc desc;
       desc.d = d_;
@@ -324,6 +327,67 @@ extern "C" float time_cpu_laplace(int N, int L, int d)
 }
 
 // =============================== Part 2 ===============================================
+
+// strong_scaling on the device clock: HIP events around `reps` launches of the caller's shape
+// (after one untimed launch), device-resident data, no host synchronisation inside the window
+extern "C" float cg_strong_scaling_events(int nblocks, int threads_per_block, int N, int L, int d, int reps)
+{
+  CG_REQUIRE(N >= 1 && nblocks >= 1 && threads_per_block >= 1 && threads_per_block <= 1024 && reps >= 1,
+             "need N, nblocks, reps >= 1 and 1 <= threads_per_block <= 1024");
+  float *x = nullptr, *b = nullptr;
+  CHECK(hipMalloc((void **)&x, ((size_t)N + 1) * sizeof(float)));
+  CHECK(hipMalloc((void **)&b, ((size_t)N + 1) * sizeof(float)));
+  fill_uniform(x, (unsigned long long)N, 1u, nullptr);
+  CHECK(hipMemset(b, 0, ((size_t)N + 1) * sizeof(float)));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  cgamd_launch_laplace_compat(b, x, (unsigned)d, (unsigned)L, (unsigned)N, 1u, (unsigned)nblocks,
+                              (unsigned)threads_per_block);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < reps; i++)
+    cgamd_launch_laplace_compat(b, x, (unsigned)d, (unsigned)L, (unsigned)N, 1u, (unsigned)nblocks,
+                                (unsigned)threads_per_block);
+  CHECK(hipEventRecord(e1, nullptr));
+  CHECK(hipEventSynchronize(e1));
+  CHECK(hipGetLastError());
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  CHECK(hipEventDestroy(e0));
+  CHECK(hipEventDestroy(e1));
+  CHECK(hipFree(x));
+  CHECK(hipFree(b));
+  return ms * 1000.0f / (float)reps;
+}
+
+// the same measurement for the tiled stencil the library itself uses for a whole grid
+extern "C" float cg_laplace_time_events(int L, int d, int index_mode, int reps)
+{
+  const unsigned long long N = grid_points(L, d);
+  CG_REQUIRE(reps >= 1, "need reps >= 1");
+  float *x = nullptr, *b = nullptr;
+  CHECK(hipMalloc((void **)&x, (N + 1) * sizeof(float)));
+  CHECK(hipMalloc((void **)&b, (N + 1) * sizeof(float)));
+  fill_uniform(x, N, 1u, nullptr);
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  laplace_apply(b, x, d, (unsigned)L, index_mode, nullptr);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < reps; i++)
+    laplace_apply(b, x, d, (unsigned)L, index_mode, nullptr);
+  CHECK(hipEventRecord(e1, nullptr));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  CHECK(hipEventDestroy(e0));
+  CHECK(hipEventDestroy(e1));
+  CHECK(hipFree(x));
+  CHECK(hipFree(b));
+  return ms * 1000.0f / (float)reps;
+}
 
 extern "C" void cg_laplace_device(float *ddf, const float *u, int d, int L, int index_mode, void *stream)
 {

@@ -610,11 +610,13 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
     float lv = 0.0f;
     if constexpr (LAYOUT == LAYOUT_LEX)
     {
-      unsigned long long rem = i;
+      // N < 2^32, so 32-bit division.  (Replacing it by shifts or a multiply-high made the
+      // kernels slower on MI355X: they are bound by the 2d neighbour loads, not by the ALU.)
+      unsigned rem = (unsigned)i;
       for (int k = 0; k < g.d; k++)
       {
         const unsigned nk = g.n[k];
-        const unsigned ck = (unsigned)(rem % nk);
+        const unsigned ck = rem % nk;
         rem /= nk;
         const long long s = (long long)g.stride[k];
         const bool last = GHOST && (k == g.d - 1);

@@ -326,6 +326,31 @@ Solver::~Solver()
 
 static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
 
+// Which engine an automatic choice takes.  The rows and planes engines give a lane four points of
+// axis 0 and a wave 256 of them, so a short axis 0 leaves lanes idle: measured on MI355X the
+// one-point-per-lane scalar engine wins below 128 points per row (d = 4, L = 64: 127 / 109 us
+// against 194 / 187 us for kernels A / B; d = 6, L = 16: 185 / 156 against 1070 / 1012) and the
+// planes engine needs 256 (d = 3, L = 128: rows 17.5 / 17.9, planes 20.2 / 22.6).  Grids below 2^18
+// points are launch-bound and take the scalar engine's shorter prologue.
+// CG_ENGINE = 1 (rows) | 2 (scalar) | 3 (planes) overrides the choice wherever that engine can run.
+static int choose_engine(bool rows_ok, bool planes_ok, bool morton4_ok, unsigned n0, unsigned long long N)
+{
+  if (morton4_ok)
+    return ENGINE_MORTON4;
+  const int forced = env_int("CG_ENGINE", 0);
+  if (forced == ENGINE_PLANES && planes_ok)
+    return ENGINE_PLANES;
+  if (forced == ENGINE_ROWS && rows_ok)
+    return ENGINE_ROWS;
+  if (forced == ENGINE_SCALAR)
+    return ENGINE_SCALAR;
+  if (planes_ok && n0 >= 256)
+    return ENGINE_PLANES;
+  if (rows_ok && n0 >= 128 && N >= (1ull << 18))
+    return ENGINE_ROWS;
+  return ENGINE_SCALAR;
+}
+
 void Solver::build_geometry()
 {
   const int d = desc_.d;
@@ -359,9 +384,7 @@ void Solver::build_geometry()
   const bool rows_ok = layout_ == LAYOUT_LEX && (n[0] % 4 == 0) && d <= CG_ROWS_MAXD + 2;
   const bool planes_ok = rows_ok && d == 3;
   const bool morton4_ok = layout_ == LAYOUT_MORTON && d >= 2 && N_ >= 4 && N_ % 4 == 0;
-  engine_ = desc_.engine == ENGINE_AUTO
-                ? (planes_ok ? ENGINE_PLANES : (rows_ok ? ENGINE_ROWS : (morton4_ok ? ENGINE_MORTON4 : ENGINE_SCALAR)))
-                : desc_.engine;
+  engine_ = desc_.engine == ENGINE_AUTO ? choose_engine(rows_ok, planes_ok, morton4_ok, n[0], N_) : desc_.engine;
   if (engine_ == ENGINE_MORTON4)
     CG_REQUIRE(morton4_ok, "the 4-per-lane Morton engine needs the Morton layout and d >= 2");
   if (engine_ == ENGINE_ROWS)
@@ -848,7 +871,9 @@ void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode
   a.u = u;
   a.out = ddf;
   const bool aligned = (((uintptr_t)u | (uintptr_t)ddf) % 16) == 0;
-  if (layout == LAYOUT_LEX && L % 4 == 0 && d == 3 && aligned && env_int("CG_STENCIL_PLANES", 1))
+  const bool rows_ok = layout == LAYOUT_LEX && L % 4 == 0 && d <= CG_ROWS_MAXD + 2 && aligned;
+  const int engine = layout == LAYOUT_LEX ? choose_engine(rows_ok, rows_ok && d == 3, false, L, sg.N) : ENGINE_SCALAR;
+  if (engine == ENGINE_PLANES)
   {
     PlanesGeom g;
     unsigned ext[3] = {L, L, L};
@@ -856,7 +881,7 @@ void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode
     make_planes_geom(ext, 0, 0, g, block, grid, R);
     launch_planes<MODE_STENCIL, false>(g, a, grid, block, R, stream);
   }
-  else if (layout == LAYOUT_LEX && L % 4 == 0 && d <= CG_ROWS_MAXD + 2 && aligned)
+  else if (engine == ENGINE_ROWS)
   {
     RowsGeom g;
     unsigned ext[CG_MAXD];

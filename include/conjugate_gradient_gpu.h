@@ -94,6 +94,13 @@ extern "C"
   void cg_fill_uniform(float *dst, unsigned long long n, unsigned int seed);
   float cg_u01_host(unsigned int seed, unsigned long long i);
 
+  /* strong_scaling (julia.cu:16-30) on the device clock: mean microseconds of one stencil launch of
+   * the caller's shape over `reps` back-to-back launches, HIP events, one untimed launch first.
+   * cg_laplace_time_events: the same for the tiled whole-grid stencil (what laplace_gpu_jl runs
+   * when the launch covers the grid). */
+  float cg_strong_scaling_events(int nblocks, int threads_per_block, int N, int L, int d, int reps);
+  float cg_laplace_time_events(int L, int d, int index_mode, int reps);
+
   /* --- solver object: the fused two-kernel iteration on device-resident vectors -------- */
 
   typedef struct cg_solver cg_solver;

@@ -47,3 +47,15 @@ def pkg():
 @pytest.fixture(scope="session")
 def lib(pkg):
     return pkg.load_library()
+
+
+@pytest.fixture(params=["auto", "rows", "planes"])
+def engine_env(request, monkeypatch):
+    """Run a test once per lexicographic engine: the automatic choice (which sends the small grids
+    the oracle can check to the scalar engine) and the rows / planes engines forced wherever the
+    grid allows them (CG_ENGINE is ignored where it does not)."""
+    if request.param == "auto":
+        monkeypatch.delenv("CG_ENGINE", raising=False)
+    else:
+        monkeypatch.setenv("CG_ENGINE", {"rows": "1", "planes": "3"}[request.param])
+    return request.param

@@ -79,7 +79,7 @@ STENCIL_CASES = [(1000, 1), (1024, 1), (4, 1), (10, 2), (5, 3), (64, 2), (256, 2
 
 
 @pytest.mark.parametrize("L,d", STENCIL_CASES)
-def test_stencil_bit_exact(lib, oracle, L, d):
+def test_stencil_bit_exact(lib, oracle, engine_env, L, d):
     N = L ** d
     rng = np.random.default_rng(L * 31 + d)
     u = rng.standard_normal(N).astype(np.float32)
@@ -136,7 +136,7 @@ def test_stencil_sin_and_square_reference_properties(lib):
 # ---- CG --------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "cg_cpu_*.npz"))))
-def test_cg_recovers_golden_solution(lib, oracle, path):
+def test_cg_recovers_golden_solution(lib, oracle, engine_env, path):
     """b from the reference's fixtures; the GPU float CG must recover x (tests.cu:466-501)."""
     g = np.load(path)
     L, d = int(g["L"]), int(g["d"])
@@ -300,7 +300,7 @@ def test_mixed_precision_matches_fp64_reference(lib, oracle):
 # ---- size-independent properties at larger sizes ---------------------------------------
 
 @pytest.mark.parametrize("L,d", [(2048, 2), (128, 3), (32, 4)])
-def test_stencil_linearity_and_symmetry_large(lib, L, d):
+def test_stencil_linearity_and_symmetry_large(lib, engine_env, L, d):
     """<A u, v> == <u, A v> and A(u+v) == A u + A v up to rounding, at sizes the oracle skips."""
     N = L ** d
     gen = torch.Generator(device="cuda").manual_seed(1)
