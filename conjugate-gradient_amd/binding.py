@@ -23,7 +23,7 @@ EXPORTS = [
     "cg_solver_finish", "cg_solver_sync", "cg_solver_time_kernels", "cg_solver_begin_local",
     "cg_solver_reduce", "cg_solver_bind_sums", "cg_solver_bind_partials", "cg_solver_init_state", "cg_solver_add_iterations",
     "cg_solver_kernel_A", "cg_solver_kernel_B", "cg_solver_r", "cg_solver_p",
-    "cg_links_box_bytes", "cg_links_alloc", "cg_links_free", "cg_links_export", "cg_links_open",
+    "cg_links_box_bytes", "cg_links_alloc", "cg_links_free", "cg_links_peer_ok", "cg_links_export", "cg_links_open",
     "cg_links_close", "cg_solver_bind_links", "cg_solver_exchange", "cg_solver_links_error",
     "cg_solver_links_times",
 ]
@@ -144,6 +144,8 @@ class Library:
             getattr(c, f).argtypes = [vp]
         for f in ("cg_links_alloc", "cg_links_free", "cg_links_export", "cg_links_open", "cg_links_close"):
             getattr(c, f).restype = i32
+        c.cg_links_peer_ok.argtypes = [i32]
+        c.cg_links_peer_ok.restype = i32
         c.cg_solver_bind_links.argtypes = [vp, i32, i32, C.POINTER(C.c_void_p)]
         c.cg_solver_bind_links.restype = None
         c.cg_solver_exchange.argtypes = [vp, i32, i32]
@@ -205,6 +207,9 @@ class Library:
         if e or not box.value:
             raise RuntimeError(f"cg_links_alloc({nbytes}) failed with hipError {e}")
         return box.value
+
+    def links_peer_ok(self, peer_device):
+        return bool(self.c.cg_links_peer_ok(int(peer_device)))
 
     def links_free(self, box):
         self.c.cg_links_free(_ptr(box))

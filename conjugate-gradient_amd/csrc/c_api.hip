@@ -476,6 +476,7 @@ extern "C" float *cg_solver_p(cg_solver *s, int which) { return s->impl.p(which)
 extern "C" size_t cg_links_box_bytes(const cg_solver_desc *desc) { return links_box_bytes(Solver::plane_of(to_desc(desc))); }
 extern "C" int cg_links_alloc(size_t bytes, void **box) { return links_alloc(bytes, box); }
 extern "C" int cg_links_free(void *box) { return links_free(box); }
+extern "C" int cg_links_peer_ok(int peer_device) { return links_peer_ok(peer_device); }
 extern "C" int cg_links_export(void *box, unsigned char *handle64) { return links_export(box, handle64); }
 extern "C" int cg_links_open(const unsigned char *handle64, void **box) { return links_open(handle64, box); }
 extern "C" int cg_links_close(void *box) { return links_close(box); }

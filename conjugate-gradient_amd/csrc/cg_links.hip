@@ -166,29 +166,55 @@ static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handles travel as 64 bytes")
 int links_alloc(size_t bytes, void **box)
 {
   *box = nullptr;
-  // memory that no cache of this GPU keeps: remote ranks write it while local kernels poll it
-  hipError_t e = hipExtMallocWithFlags(box, bytes, hipDeviceMallocUncached);
-  if (e != hipSuccess)
+  // memory that no cache of this GPU keeps (remote ranks write it while local kernels poll it) and
+  // that can be handed to another process: uncached first, fine-grained if that cannot be exported
+  const unsigned flags[2] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained};
+  hipError_t e = hipErrorUnknown;
+  for (int k = 0; k < 2; k++)
   {
+    void *p = nullptr;
+    e = hipExtMallocWithFlags(&p, bytes, flags[k]);
+    if (e != hipSuccess)
+    {
+      (void)hipGetLastError();
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, p);
+    if (e == hipSuccess)
+      e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess)
+      e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+    {
+      *box = p;
+      return 0;
+    }
     (void)hipGetLastError();
-    e = hipExtMallocWithFlags(box, bytes, hipDeviceMallocFinegrained);
-  }
-  if (e != hipSuccess)
-  {
-    (void)hipGetLastError();
-    *box = nullptr;
-    return (int)e;
-  }
-  e = hipMemset(*box, 0, bytes);
-  if (e == hipSuccess)
-    e = hipDeviceSynchronize();
-  if (e != hipSuccess)
-  {
-    (void)hipGetLastError();
-    (void)hipFree(*box);
-    *box = nullptr;
+    (void)hipFree(p);
   }
   return (int)e;
+}
+
+// can kernels on the current device store into memory of `peer_device`?  Enables the access.
+int links_peer_ok(int peer_device)
+{
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess)
+    return 0;
+  if (dev == peer_device)
+    return 1;
+  int can = 0;
+  e = hipDeviceCanAccessPeer(&can, dev, peer_device);
+  if (e != hipSuccess || !can)
+  {
+    (void)hipGetLastError();
+    return 0;
+  }
+  e = hipDeviceEnablePeerAccess(peer_device, 0);
+  (void)hipGetLastError(); // "already enabled" is fine
+  return (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ? 1 : 0;
 }
 
 int links_free(void *box)

@@ -101,6 +101,7 @@ __global__ void k_exchange(const LinkArgs L);
 // value (0 = success) instead of terminating, so that a caller can fall back to collectives.
 int links_alloc(size_t bytes, void **box);
 int links_free(void *box);
+int links_peer_ok(int peer_device);                          // 1 if this device can write that one's memory
 int links_export(void *box, unsigned char handle[64]);     // for another process on this node
 int links_open(const unsigned char handle[64], void **box);
 int links_close(void *box);

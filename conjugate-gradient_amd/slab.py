@@ -21,6 +21,7 @@ the gloo backend.
 """
 import contextlib
 import os
+import socket
 
 import torch
 import torch.distributed as dist
@@ -189,22 +190,27 @@ class SlabCG:
         except Exception as e:  # noqa: BLE001 -- any failure means "use the collectives"
             ok, self.links_reason = 0, repr(e)
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, (ok, os.getpid(), handle), group=self.group)
+        me = (ok, socket.gethostname(), os.getpid(), torch.cuda.current_device(), handle)
+        dist.all_gather_object(gathered, me, group=self.group)
         boxes, self._opened = [], []
-        if all(g[0] for g in gathered):
+        if not all(g[0] for g in gathered):
+            ok = 0
+        elif any(g[1] != me[1] for g in gathered):
+            ok, self.links_reason = 0, "ranks on different hosts"
+        else:
             try:
-                for j, (_, pid, h) in enumerate(gathered):
+                for j, (_, _, pid, dev, h) in enumerate(gathered):
                     if j == self.rank:
                         boxes.append(self._box)
-                    else:
-                        # an IPC handle cannot be opened by the process that made it
-                        p = lib.links_open(h)
-                        self._opened.append(p)
-                        boxes.append(p)
+                        continue
+                    if not lib.links_peer_ok(dev):
+                        raise RuntimeError(f"device {me[3]} cannot write the memory of device {dev}")
+                    # (an IPC handle cannot be opened by the process that made it: own box above)
+                    p = lib.links_open(h)
+                    self._opened.append(p)
+                    boxes.append(p)
             except Exception as e:  # noqa: BLE001
                 ok, self.links_reason = 0, repr(e)
-        else:
-            ok = 0
         if not self._all_agree(ok):
             self._release_links()
             return False

@@ -167,6 +167,7 @@ extern "C"
   size_t cg_links_box_bytes(const cg_solver_desc *desc);
   int cg_links_alloc(size_t bytes, void **box);            /* device memory no cache keeps, zeroed */
   int cg_links_free(void *box);
+  int cg_links_peer_ok(int peer_device);                   /* 1 if the current device can write that device's memory (enables it) */
   int cg_links_export(void *box, unsigned char *handle64); /* for the other processes of the node */
   int cg_links_open(const unsigned char *handle64, void **box);
   int cg_links_close(void *box);
