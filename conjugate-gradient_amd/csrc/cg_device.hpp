@@ -102,6 +102,9 @@ struct RowsGeom
   unsigned nk[CG_ROWS_MAXD];
   unsigned long long sk[CG_ROWS_MAXD];
   int has_lo, has_hi;
+  // packed mode (rows shorter than a wave's 256 points): `sub` lanes hold one row, a workgroup
+  // holds `cpg` columns side by side; `ncols` columns in all
+  unsigned sub, cpg, ncols;
 };
 
 struct ScalarGeom
@@ -330,15 +333,20 @@ __device__ __forceinline__ float axis_term(float up, float c, float um) { return
 // GHOST: the vectors own one extra hyperplane below and above the last axis (zero on a
 // global face, the neighbour rank's data on a slab face, has_lo/has_hi).
 // D: compile-time dimension (1..3), 0 = run-time g.d (>= 4).
+// PACK (d >= 3, n0 = 16, 32, 64 or 128): a row of axis 0 occupies only n0/4 lanes, so the lanes of
+// a workgroup hold several columns (different coordinates of axes >= 2) side by side; a row
+// never crosses a wave, its two ends are grid faces, and everything that depends on the
+// column (base offset, face masks) is per lane instead of per workgroup.
 
 __device__ __forceinline__ float4 sel4(bool c, float4 v)
 {
   return c ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-template <int MODE, bool GHOST, int D, int POL>
+template <int MODE, bool GHOST, int D, int POL, bool PACK = false>
 __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
 {
+  static_assert(!PACK || D == 0 || D == 3, "packed rows exist for d >= 3 only");
   __shared__ double sh[8];
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr bool NT = POL == POL_KEEP_R; // x, the stores of r and of p_new
@@ -380,8 +388,23 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
   {
     const unsigned seg = item % g.bpc;
     const unsigned col = item / g.bpc;
-    const unsigned xc = col % g.nxc;
-    unsigned hi = col / g.nxc;
+    unsigned xc = 0, hi, x0;
+    bool act;
+    if constexpr (PACK)
+    {
+      const unsigned cs = (unsigned)tid / g.sub;      // column within this workgroup's group
+      const unsigned c = col * g.cpg + cs;
+      act = c < g.ncols;
+      hi = act ? c : g.ncols - 1u;
+      x0 = ((unsigned)tid % g.sub) * 4u;
+    }
+    else
+    {
+      xc = col % g.nxc;
+      hi = col / g.nxc;
+      x0 = (xc * blockDim.x + tid) * 4u;
+      act = x0 < g.n0;
+    }
     long long base = 0;
     unsigned okm = 0, okp = 0;
     bool st_lo = false, st_hi = false;
@@ -406,9 +429,7 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
     const long long y1 = (long long)((unsigned long long)(seg + 1) * g.n1 / g.bpc);
     if (y0 >= y1)
       continue;
-    const unsigned x0 = (xc * blockDim.x + tid) * 4u;
-    const bool act = x0 < g.n0;
-    const long long col0 = base + (act ? x0 : g.n0 - 4u);
+    const long long col0 = base + ((PACK || act) ? x0 : g.n0 - 4u);
     const bool el = act && lane == 0 && x0 > 0;
     const bool er = act && lane == 63 && x0 + 4 < g.n0;
     const bool edge = (el || er) && !(CG_DBG & 1);
@@ -477,6 +498,11 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
         lft = ec;
       if (rightmost)
         rgt = (lane == 63) ? ec : 0.0f;
+      if constexpr (PACK)
+      {
+        if (x0 == 0) // first lane of a packed row: the grid face, not the previous lane's row
+          lft = 0.0f;
+      }
 
       float4 lv;
       lv.x = 0.0f + axis_term(pc.y, pc.x, lft);

@@ -126,6 +126,9 @@ static int resident_blocks()
   return std::min(cus * per_cu, max_blocks());
 }
 
+// rows shorter than a wave's 256 points that the rows engine can pack several to a wave
+static bool rows_packable(int d, unsigned n0) { return d >= 3 && (n0 == 16 || n0 == 32 || n0 == 64 || n0 == 128); }
+
 // columns x segments decomposition of the rows engine (see cg_device.hpp)
 static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, RowsGeom &g, int &block, int &grid)
 {
@@ -144,6 +147,16 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
     g.sk[k - 2] = stride;
     stride *= n[k];
     ncols *= n[k];
+  }
+  // rows shorter than a wave: several columns side by side in one workgroup (see k_rows, PACK)
+  if (rows_packable(d, n[0]) && ncols < (1ull << 32) && env_int("CG_ROWS_PACK", 1))
+  {
+    block = 256;
+    g.sub = lanes;
+    g.cpg = 256u / lanes;
+    g.ncols = (unsigned)ncols;
+    g.nxc = 1;
+    ncols = (ncols + g.cpg - 1) / g.cpg; // column groups
   }
   // scale the resident-workgroup target by the workgroup size (it is counted in 256-thread units)
   const unsigned long long target = (unsigned long long)resident_blocks() * (256 / block);
@@ -327,13 +340,15 @@ Solver::~Solver()
 static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
 
 // Which engine an automatic choice takes.  The rows and planes engines give a lane four points of
-// axis 0 and a wave 256 of them, so a short axis 0 leaves lanes idle: measured on MI355X the
-// one-point-per-lane scalar engine wins below 128 points per row (d = 4, L = 64: 127 / 109 us
-// against 194 / 187 us for kernels A / B; d = 6, L = 16: 185 / 156 against 1070 / 1012) and the
-// planes engine needs 256 (d = 3, L = 128: rows 17.5 / 17.9, planes 20.2 / 22.6).  Grids below 2^18
+// axis 0 and a wave 256 of them, so a short axis 0 leaves lanes idle unless the rows engine can pack
+// several rows into a wave (d >= 3 and n0 = 16, 32, 64, 128).  Measured on MI355X, kernels A / B in
+// microseconds, rows against the one-point-per-lane scalar engine: d = 4, L = 64 packed 69 / 81
+// against 124 / 103; d = 5, L = 32 packed 209 / 199 against 354 / 304; d = 6, L = 16 a tie; unpacked
+// rows of 64 points (before packing existed) lost 194 / 187 to 127 / 109.  The planes engine needs
+// 256 points per row (d = 3, L = 128: packed rows 11.7 / 12.2, planes 20.1 / 22.8).  Grids below 2^19
 // points are launch-bound and take the scalar engine's shorter prologue.
 // CG_ENGINE = 1 (rows) | 2 (scalar) | 3 (planes) overrides the choice wherever that engine can run.
-static int choose_engine(bool rows_ok, bool planes_ok, bool morton4_ok, unsigned n0, unsigned long long N)
+static int choose_engine(bool rows_ok, bool planes_ok, bool morton4_ok, int d, unsigned n0, unsigned long long N)
 {
   if (morton4_ok)
     return ENGINE_MORTON4;
@@ -346,7 +361,7 @@ static int choose_engine(bool rows_ok, bool planes_ok, bool morton4_ok, unsigned
     return ENGINE_SCALAR;
   if (planes_ok && n0 >= 256)
     return ENGINE_PLANES;
-  if (rows_ok && n0 >= 128 && N >= (1ull << 18))
+  if (rows_ok && (n0 >= 128 || rows_packable(d, n0)) && N >= (1ull << 19))
     return ENGINE_ROWS;
   return ENGINE_SCALAR;
 }
@@ -384,7 +399,7 @@ void Solver::build_geometry()
   const bool rows_ok = layout_ == LAYOUT_LEX && (n[0] % 4 == 0) && d <= CG_ROWS_MAXD + 2;
   const bool planes_ok = rows_ok && d == 3;
   const bool morton4_ok = layout_ == LAYOUT_MORTON && d >= 2 && N_ >= 4 && N_ % 4 == 0;
-  engine_ = desc_.engine == ENGINE_AUTO ? choose_engine(rows_ok, planes_ok, morton4_ok, n[0], N_) : desc_.engine;
+  engine_ = desc_.engine == ENGINE_AUTO ? choose_engine(rows_ok, planes_ok, morton4_ok, d, n[0], N_) : desc_.engine;
   if (engine_ == ENGINE_MORTON4)
     CG_REQUIRE(morton4_ok, "the 4-per-lane Morton engine needs the Morton layout and d >= 2");
   if (engine_ == ENGINE_ROWS)
@@ -430,6 +445,14 @@ VecArgs Solver::args() const
 template <int MODE, bool GHOST, int POL>
 static void launch_rows_pol(const RowsGeom &g, const VecArgs &a, int grid, int block, hipStream_t s)
 {
+  if (g.sub)
+  {
+    if (g.d == 3)
+      hipLaunchKernelGGL((k_rows<MODE, GHOST, 3, POL, true>), dim3(grid), dim3(block), 0, s, g, a);
+    else
+      hipLaunchKernelGGL((k_rows<MODE, GHOST, 0, POL, true>), dim3(grid), dim3(block), 0, s, g, a);
+    return;
+  }
   switch (g.d)
   {
   case 1: hipLaunchKernelGGL((k_rows<MODE, GHOST, 1, POL>), dim3(grid), dim3(block), 0, s, g, a); break;
@@ -872,7 +895,7 @@ void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode
   a.out = ddf;
   const bool aligned = (((uintptr_t)u | (uintptr_t)ddf) % 16) == 0;
   const bool rows_ok = layout == LAYOUT_LEX && L % 4 == 0 && d <= CG_ROWS_MAXD + 2 && aligned;
-  const int engine = layout == LAYOUT_LEX ? choose_engine(rows_ok, rows_ok && d == 3, false, L, sg.N) : ENGINE_SCALAR;
+  const int engine = layout == LAYOUT_LEX ? choose_engine(rows_ok, rows_ok && d == 3, false, d, L, sg.N) : ENGINE_SCALAR;
   if (engine == ENGINE_PLANES)
   {
     PlanesGeom g;
