@@ -52,7 +52,7 @@ def run_links(lib, ext_of, nranks, bs, iters, use_graph, engine=0):
 @pytest.mark.parametrize("use_graph", [False, True])
 # two ranks only: a process has four hardware queues, and two spinning solvers whose streams share
 # one would wait for each other forever (more ranks: the multi-process test below)
-@pytest.mark.parametrize("L,d,nranks", [(16, 2, 2), (64, 2, 2), (16, 3, 2), (10, 2, 2), (6, 3, 2), (8, 4, 2)])
+@pytest.mark.parametrize("L,d,nranks", [(16, 2, 2), (64, 2, 2), (16, 3, 2), (10, 2, 2), (6, 3, 2), (8, 4, 2), (32, 3, 2)])
 def test_linked_ranks_match_single_gpu_and_oracle(lib, oracle, engine_env, L, d, nranks, use_graph):
     N = L ** d
     rng = np.random.default_rng(L + d)

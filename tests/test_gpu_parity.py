@@ -75,7 +75,7 @@ def test_inner_product_host_pointer(lib):
 # ---- stencil ---------------------------------------------------------------------------
 
 STENCIL_CASES = [(1000, 1), (1024, 1), (4, 1), (10, 2), (5, 3), (64, 2), (256, 2), (12, 3), (16, 3), (32, 3),
-                 (8, 4), (6, 4), (4, 5), (2, 10), (260, 2), (100, 3)]
+                 (8, 4), (6, 4), (4, 5), (2, 10), (260, 2), (100, 3), (16, 4), (64, 3), (128, 3), (16, 5)]
 
 
 @pytest.mark.parametrize("L,d", STENCIL_CASES)

@@ -71,7 +71,7 @@ def run_virtual(pkg, lib, L, d, nranks, b, iters, engine=0):
     return x, outs[0][0], outs[0][2]
 
 
-@pytest.mark.parametrize("L,d,nranks", [(16, 2, 2), (64, 2, 4), (16, 3, 2), (16, 3, 4), (10, 2, 2), (6, 3, 3), (8, 4, 2)])
+@pytest.mark.parametrize("L,d,nranks", [(16, 2, 2), (64, 2, 4), (16, 3, 2), (16, 3, 4), (10, 2, 2), (6, 3, 3), (8, 4, 2), (32, 3, 2), (16, 4, 2)])
 def test_virtual_ranks_match_single_gpu_and_oracle(pkg, lib, oracle, engine_env, L, d, nranks):
     N = L ** d
     rng = np.random.default_rng(L + d)
