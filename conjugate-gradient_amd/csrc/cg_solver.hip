@@ -16,7 +16,9 @@ namespace cgamd
 
 // ---- small kernels -------------------------------------------------------------------------
 
-// per-block partials of v.w; 16-byte loads when both pointers allow it
+// per-block partials of v.w; 16-byte loads when both pointers allow it.  Four independent
+// 16-byte loads per vector are in flight per lane and feed four accumulators that are added in a
+// fixed order at the end, so the result depends on the launch shape only (the callers fix it).
 __global__ void __launch_bounds__(256) k_dot(const float *__restrict__ v, const float *__restrict__ w,
                                              unsigned long long n, int vec4, double *__restrict__ part_out)
 {
@@ -27,17 +29,31 @@ __global__ void __launch_bounds__(256) k_dot(const float *__restrict__ v, const 
   if (vec4)
   {
     const unsigned long long n4 = n >> 2;
-    for (unsigned long long j = i; j < n4; j += step)
+    const float4 *v4 = reinterpret_cast<const float4 *>(v);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    const bool same = v == w;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    unsigned long long j = i;
+    for (; j + 3 * step < n4; j += 4 * step)
     {
-      const float4 a = reinterpret_cast<const float4 *>(v)[j];
-      const float4 b = reinterpret_cast<const float4 *>(w)[j];
-      acc = fmaf(a.x, b.x, acc);
-      acc = fmaf(a.y, b.y, acc);
-      acc = fmaf(a.z, b.z, acc);
-      acc = fmaf(a.w, b.w, acc);
+      const float4 p0 = load4<true>(v + 4 * j), p1 = load4<true>(v + 4 * (j + step));
+      const float4 p2 = load4<true>(v + 4 * (j + 2 * step)), p3 = load4<true>(v + 4 * (j + 3 * step));
+      const float4 q0 = same ? p0 : load4<true>(w + 4 * j), q1 = same ? p1 : load4<true>(w + 4 * (j + step));
+      const float4 q2 = same ? p2 : load4<true>(w + 4 * (j + 2 * step));
+      const float4 q3 = same ? p3 : load4<true>(w + 4 * (j + 3 * step));
+      a0 = fmaf(p0.w, q0.w, fmaf(p0.z, q0.z, fmaf(p0.y, q0.y, fmaf(p0.x, q0.x, a0))));
+      a1 = fmaf(p1.w, q1.w, fmaf(p1.z, q1.z, fmaf(p1.y, q1.y, fmaf(p1.x, q1.x, a1))));
+      a2 = fmaf(p2.w, q2.w, fmaf(p2.z, q2.z, fmaf(p2.y, q2.y, fmaf(p2.x, q2.x, a2))));
+      a3 = fmaf(p3.w, q3.w, fmaf(p3.z, q3.z, fmaf(p3.y, q3.y, fmaf(p3.x, q3.x, a3))));
     }
-    for (unsigned long long j = (n4 << 2) + i; j < n; j += step)
-      acc = fmaf(v[j], w[j], acc);
+    for (; j < n4; j += step)
+    {
+      const float4 p0 = v4[j], q0 = w4[j];
+      a0 = fmaf(p0.w, q0.w, fmaf(p0.z, q0.z, fmaf(p0.y, q0.y, fmaf(p0.x, q0.x, a0))));
+    }
+    acc = (a0 + a1) + (a2 + a3);
+    for (unsigned long long k = (n4 << 2) + i; k < n; k += step)
+      acc = fmaf(v[k], w[k], acc);
   }
   else
   {
