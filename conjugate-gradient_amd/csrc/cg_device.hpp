@@ -452,8 +452,20 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
     // the element just outside this wave's span of row yy (rows inside the grid only)
     auto ldedge = [&](long long yy) -> float {
       float e = 0.0f;
-      if (edge)
-        e = src.ld1(col0 + yy * n0 + eoff);
+      if constexpr (D == 1)
+      {
+        // a long 1-D grid is cut into "rows" of n0 points only to march through it: the rows are
+        // contiguous in memory and the ends of a row are ordinary neighbours, except at the two
+        // ends of the whole grid
+        const bool e1 = act && ((lane == 0 && (x0 > 0 || yy > 0)) || (lane == 63 && (x0 + 4 < g.n0 || yy + 1 < n1)));
+        if (e1 && !(CG_DBG & 1))
+          e = src.ld1(col0 + yy * n0 + eoff);
+      }
+      else
+      {
+        if (edge)
+          e = src.ld1(col0 + yy * n0 + eoff);
+      }
       return e;
     };
 

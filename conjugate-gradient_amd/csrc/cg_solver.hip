@@ -152,6 +152,16 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
   g.d = d;
   g.n0 = n[0];
   g.n1 = d >= 2 ? n[1] : 1;
+  // a long 1-D grid marches through "rows" of 1024 points (see ldedge in k_rows): consecutive rows
+  // of a segment are contiguous memory, and the next row's loads are in flight while one is computed
+  unsigned folded[2] = {1024u, 0u};
+  if (d == 1 && n[0] % 1024u == 0 && n[0] >= (1u << 20) && env_int("CG_ROWS_FOLD_1D", 1))
+  {
+    folded[1] = n[0] / 1024u;
+    g.n0 = folded[0];
+    g.n1 = folded[1];
+    n = folded;
+  }
   const unsigned lanes = n[0] / 4;
   block = (int)std::min(256u, (lanes + 63) / 64 * 64);
   block = std::max(64, std::min(256, env_int("CG_ROWS_BLOCK", block) / 64 * 64)); // k_rows is bounded to 256 threads

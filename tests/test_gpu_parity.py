@@ -75,7 +75,8 @@ def test_inner_product_host_pointer(lib):
 # ---- stencil ---------------------------------------------------------------------------
 
 STENCIL_CASES = [(1000, 1), (1024, 1), (4, 1), (10, 2), (5, 3), (64, 2), (256, 2), (12, 3), (16, 3), (32, 3),
-                 (8, 4), (6, 4), (4, 5), (2, 10), (260, 2), (100, 3), (16, 4), (64, 3), (128, 3), (16, 5)]
+                 (8, 4), (6, 4), (4, 5), (2, 10), (260, 2), (100, 3), (16, 4), (64, 3), (128, 3), (16, 5),
+                 (1 << 20, 1), (3 << 20, 1)]
 
 
 @pytest.mark.parametrize("L,d", STENCIL_CASES)
@@ -179,6 +180,29 @@ def test_engines_agree_with_emulation(lib, oracle, L, d, engine):
         assert np.all(np.abs(got - xt) < 1e-3)
     assert rel_l2(got, xe) <= 2e-4
     s.close()
+
+
+def test_long_1d_grid_marches_in_rows(lib, oracle):
+    """1-D grids of 2^20 points and more are cut into contiguous 1024-point rows by the rows engine:
+    same stencil bits as the oracle (in the stencil cases above) and the same CG as the
+    one-point-per-lane engine."""
+    N = 3 << 20
+    b = np.random.default_rng(4).random(N).astype(np.float32)
+    bd = dev(b)
+    outs = []
+    for engine in (1, 2):
+        s = lib.make_solver([N], engine=engine)
+        x = torch.zeros(N, dtype=torch.float32, device="cuda")
+        s.begin(bd.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.iterate(50, use_graph=True)
+        iters, res, hist = s.finish(hist_len=64)
+        assert iters == 50
+        outs.append((x.cpu().numpy(), np.array(hist)))
+        s.close()
+    assert np.allclose(outs[0][1], outs[1][1], rtol=1e-4)
+    assert rel_l2(outs[0][0], outs[1][0]) <= 1e-4
+    xe, _, _, histe = oracle.cg_f32(b, N, 1, maxit=50, hist_len=64, rel=0.0)
+    assert np.allclose(outs[0][1], histe[:50], rtol=1e-3)
 
 
 def test_graph_and_plain_launches_are_bit_identical(lib, oracle):
