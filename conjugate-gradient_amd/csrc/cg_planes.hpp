@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
   // [plane parity][wave][0 = first row, 1 = last row][lane]
   __shared__ float4 halo[2][CG_PLANES_MAX_WAVES][2][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
-  constexpr bool NT = POL == POL_KEEP_R;
+  constexpr bool NT = POL != POL_PLAIN;
   Src<MODE, POL> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;

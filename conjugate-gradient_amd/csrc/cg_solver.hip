@@ -336,7 +336,9 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   // re-reads p's far neighbours, which non-temporal loads would push back to HBM
   // (the planes engine loads p once, so streaming hints pay there at any size)
   const bool keep_r = engine_ == ENGINE_PLANES || engine_ == ENGINE_MORTON4 || (N_ * sizeof(float) <= (256ull << 20) && desc_.d <= 2);
-  policy_ = env_int("CG_CACHE_POLICY", keep_r ? POL_KEEP_R : POL_PLAIN);
+  policy_ = env_int("CG_CACHE_POLICY", engine_ == ENGINE_PLANES ? POL_KEEP_RP : (keep_r ? POL_KEEP_R : POL_PLAIN));
+  if (policy_ == POL_KEEP_RP && engine_ != ENGINE_PLANES)
+    policy_ = POL_KEEP_R; // the third policy exists for the planes engine only
   sumA_ = partA_;
   sumB_ = partB_;
   nA_ = nB_ = grid_;
@@ -510,7 +512,9 @@ template <int MODE, bool GHOST>
 static void launch_planes(const PlanesGeom &g, const VecArgs &a, int grid, int block, int R, hipStream_t s,
                           int pol = POL_PLAIN)
 {
-  if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
+  if (pol == POL_KEEP_RP && MODE != MODE_STENCIL)
+    launch_planes_pol<MODE, GHOST, POL_KEEP_RP>(g, a, grid, block, R, s);
+  else if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
     launch_planes_pol<MODE, GHOST, POL_KEEP_R>(g, a, grid, block, R, s);
   else
     launch_planes_pol<MODE, GHOST, POL_PLAIN>(g, a, grid, block, R, s);
