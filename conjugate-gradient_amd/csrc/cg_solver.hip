@@ -332,10 +332,10 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   CHECK(hipMemsetAsync(p0_base_, 0, buflen_ * sizeof(float), stream_));
   CHECK(hipMemsetAsync(p1_base_, 0, buflen_ * sizeof(float), stream_));
   build_geometry();
-  // r can only stay in the 256 MiB Infinity Cache if it fits; the rows engine in d >= 3 also
-  // re-reads p's far neighbours, which non-temporal loads would push back to HBM
-  // (the planes engine loads p once, so streaming hints pay there at any size)
-  const bool keep_r = engine_ == ENGINE_PLANES || engine_ == ENGINE_MORTON4 || (N_ * sizeof(float) <= (256ull << 20) && desc_.d <= 2);
+  // Streaming hints: r stays in the 256 MiB Infinity Cache only if it fits, but in 1-D and 2-D the
+  // hints pay at any size (16384 x 8192: +2.6 %, 16384^2: even); the rows engine in d >= 3 re-reads
+  // p's far neighbours, which non-temporal loads would push back to HBM, so it uses plain accesses
+  const bool keep_r = engine_ == ENGINE_PLANES || engine_ == ENGINE_MORTON4 || desc_.d <= 2;
   policy_ = env_int("CG_CACHE_POLICY", engine_ == ENGINE_PLANES ? POL_KEEP_RP : (keep_r ? POL_KEEP_R : POL_PLAIN));
   if (policy_ == POL_KEEP_RP && engine_ != ENGINE_PLANES)
     policy_ = POL_KEEP_R; // the third policy exists for the planes engine only
