@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
       }
       else if constexpr (MODE == MODE_A)
       {
-        store4<false>(p_new + i, cc);
+        store4<NT>(p_new + i, cc); // streams: kernel B re-reads it only after the whole vector was written
         acc = fmaf(cc.x, lv.x, acc);
         acc = fmaf(cc.y, lv.y, acc);
         acc = fmaf(cc.z, lv.z, acc);
