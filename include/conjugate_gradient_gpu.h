@@ -172,6 +172,8 @@ extern "C"
   int cg_links_open(const unsigned char *handle64, void **box);
   int cg_links_close(void *box);
   /* boxes[0..world): every rank's box as mapped in this process; boxes[rank] is this rank's own.
+   * Binding restarts the exchange sequence numbers at zero on every rank, so the boxes must be
+   * freshly allocated (all zero) and all ranks must bind before any of them begins a solve.
    * world = 0 unbinds (waits for the solver's stream first). */
   void cg_solver_bind_links(cg_solver *s, int rank, int world, void *const *boxes);
   void cg_solver_exchange(cg_solver *s, int which, int force); /* step interface: enqueue one exchange */
