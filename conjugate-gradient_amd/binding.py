@@ -24,7 +24,7 @@ EXPORTS = [
     "cg_solver_reduce", "cg_solver_bind_sums", "cg_solver_bind_partials", "cg_solver_init_state", "cg_solver_add_iterations",
     "cg_solver_kernel_A", "cg_solver_kernel_B", "cg_solver_r", "cg_solver_p",
     "cg_links_box_bytes", "cg_links_alloc", "cg_links_free", "cg_links_peer_ok", "cg_links_export", "cg_links_open",
-    "cg_links_close", "cg_solver_bind_links", "cg_solver_exchange", "cg_solver_links_error",
+    "cg_links_close", "cg_links_poke", "cg_links_peek", "cg_solver_bind_links", "cg_solver_exchange", "cg_solver_links_error",
     "cg_solver_links_times",
 ]
 
@@ -144,6 +144,10 @@ class Library:
             getattr(c, f).argtypes = [vp]
         for f in ("cg_links_alloc", "cg_links_free", "cg_links_export", "cg_links_open", "cg_links_close"):
             getattr(c, f).restype = i32
+        c.cg_links_poke.argtypes = [vp, i32, C.c_ulonglong]
+        c.cg_links_poke.restype = i32
+        c.cg_links_peek.argtypes = [vp, i32, C.POINTER(C.c_ulonglong)]
+        c.cg_links_peek.restype = i32
         c.cg_links_peer_ok.argtypes = [i32]
         c.cg_links_peer_ok.restype = i32
         c.cg_solver_bind_links.argtypes = [vp, i32, i32, C.POINTER(C.c_void_p)]
@@ -227,6 +231,18 @@ class Library:
         if e or not box.value:
             raise RuntimeError(f"cg_links_open failed with hipError {e}")
         return box.value
+
+    def links_poke(self, box, slot, value):
+        e = self.c.cg_links_poke(_ptr(box), slot, value)
+        if e:
+            raise RuntimeError(f"cg_links_poke failed with hipError {e}")
+
+    def links_peek(self, box, slot):
+        v = C.c_ulonglong(0)
+        e = self.c.cg_links_peek(_ptr(box), slot, C.byref(v))
+        if e:
+            raise RuntimeError(f"cg_links_peek failed with hipError {e}")
+        return v.value
 
     def links_close(self, box):
         self.c.cg_links_close(_ptr(box))

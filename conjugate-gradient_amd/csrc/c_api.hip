@@ -480,6 +480,8 @@ extern "C" int cg_links_peer_ok(int peer_device) { return links_peer_ok(peer_dev
 extern "C" int cg_links_export(void *box, unsigned char *handle64) { return links_export(box, handle64); }
 extern "C" int cg_links_open(const unsigned char *handle64, void **box) { return links_open(handle64, box); }
 extern "C" int cg_links_close(void *box) { return links_close(box); }
+extern "C" int cg_links_poke(void *box, int slot, unsigned long long value) { return links_poke(box, slot, value); }
+extern "C" int cg_links_peek(void *box, int slot, unsigned long long *value) { return links_peek(box, slot, value); }
 extern "C" void cg_solver_bind_links(cg_solver *s, int rank, int world, void *const *boxes)
 {
   s->impl.bind_links(rank, world, boxes);

@@ -244,6 +244,30 @@ int links_open(const unsigned char handle[64], void **box)
   return (int)e;
 }
 
+// Host-side access to word `slot` (0..63) of a box's staging area, through the copy engines: a
+// mapping that is not usable comes back as an error code here instead of as a fault in a kernel.
+int links_poke(void *box, int slot, unsigned long long value)
+{
+  if (slot < 0 || slot >= CG_LINKS_MAX_RANKS)
+    return (int)hipErrorInvalidValue;
+  char *dst = static_cast<char *>(box) + CG_LINKS_HEADER + (size_t)slot * sizeof(value);
+  hipError_t e = hipMemcpy(dst, &value, sizeof(value), hipMemcpyDefault);
+  if (e == hipSuccess)
+    e = hipDeviceSynchronize();
+  (void)hipGetLastError();
+  return (int)e;
+}
+
+int links_peek(void *box, int slot, unsigned long long *value)
+{
+  if (slot < 0 || slot >= CG_LINKS_MAX_RANKS)
+    return (int)hipErrorInvalidValue;
+  const char *src = static_cast<const char *>(box) + CG_LINKS_HEADER + (size_t)slot * sizeof(*value);
+  const hipError_t e = hipMemcpy(value, src, sizeof(*value), hipMemcpyDefault);
+  (void)hipGetLastError();
+  return (int)e;
+}
+
 int links_close(void *box)
 {
   const hipError_t e = hipIpcCloseMemHandle(box);

@@ -84,7 +84,8 @@ struct LinkArgs
   long long budget;   // wall_clock64 ticks (100 MHz) a wait may take
 };
 
-__host__ __device__ inline size_t links_plane_pad(size_t plane) { return (plane + 63) / 64 * 64; }
+// at least 128 floats, so that the staging area always holds 64 eight-byte probe words (links_poke)
+__host__ __device__ inline size_t links_plane_pad(size_t plane) { return (plane < 128 ? 128 : (plane + 63) / 64 * 64); }
 __host__ __device__ inline size_t links_box_bytes(size_t plane)
 {
   return CG_LINKS_HEADER + 4 * links_plane_pad(plane) * sizeof(float);
@@ -105,5 +106,7 @@ int links_peer_ok(int peer_device);                          // 1 if this device
 int links_export(void *box, unsigned char handle[64]);     // for another process on this node
 int links_open(const unsigned char handle[64], void **box);
 int links_close(void *box);
+int links_poke(void *box, int slot, unsigned long long value);  // host write / read of a staging word
+int links_peek(void *box, int slot, unsigned long long *value);
 
 } // namespace cgamd

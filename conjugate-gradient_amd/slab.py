@@ -214,6 +214,27 @@ class SlabCG:
         if not self._all_agree(ok):
             self._release_links()
             return False
+        # every rank writes a token into every box through the copy engines and reads back what
+        # the others wrote into its own: a mapping that does not work shows up here as an error
+        # code or a wrong word, not as a fault in the first kernel that stores through it
+        try:
+            for j, bx in enumerate(boxes):
+                lib.links_poke(bx, self.rank, 0xC0FFEE00 + 64 * j + self.rank)
+        except Exception as e:  # noqa: BLE001
+            ok, self.links_reason = 0, repr(e)
+        ok = self._all_agree(ok)          # also: all pokes have landed before anybody peeks
+        if ok:
+            try:
+                for j in range(self.world):
+                    if lib.links_peek(self._box, j) != 0xC0FFEE00 + 64 * self.rank + j:
+                        raise RuntimeError(f"probe word from rank {j} did not arrive")
+                    lib.links_poke(self._box, j, 0)
+            except Exception as e:  # noqa: BLE001
+                ok, self.links_reason = 0, repr(e)
+            ok = self._all_agree(ok)
+        if not ok:
+            self._release_links()
+            return False
         solver.bind_links(self.rank, boxes)
         self.links = True
         return True

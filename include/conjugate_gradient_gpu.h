@@ -171,6 +171,10 @@ extern "C"
   int cg_links_export(void *box, unsigned char *handle64); /* for the other processes of the node */
   int cg_links_open(const unsigned char *handle64, void **box);
   int cg_links_close(void *box);
+  /* host-side write / read (copy engines) of probe word `slot` (0..63) at the start of a box's staging
+   * area: lets the ranks check every mapping before the first kernel stores through it */
+  int cg_links_poke(void *box, int slot, unsigned long long value);
+  int cg_links_peek(void *box, int slot, unsigned long long *value);
   /* boxes[0..world): every rank's box as mapped in this process; boxes[rank] is this rank's own.
    * Binding restarts the exchange sequence numbers at zero on every rank, so the boxes must be
    * freshly allocated (all zero) and all ranks must bind before any of them begins a solve.
