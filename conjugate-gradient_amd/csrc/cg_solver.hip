@@ -424,6 +424,22 @@ void Solver::build_geometry()
     CG_REQUIRE(bits * d <= 32, "the Morton index must fit 32 bits");
   }
 
+  // small grids: whole iterations inside one workgroup (cg_small.hpp); automatic engine choice only
+  small_ = desc_.engine == ENGINE_AUTO && !desc_.has_lo && !desc_.has_hi && N_ <= (size_t)CG_SMALL_MAX &&
+           d <= CG_SMALL_MAXD && env_int("CG_SMALL", 1);
+  if (small_)
+  {
+    memset(&smg_, 0, sizeof(smg_));
+    smg_.d = d;
+    smg_.N = (unsigned)N_;
+    for (int k = 0; k < d; k++)
+    {
+      smg_.n[k] = n[k];
+      smg_.stride[k] = (unsigned)sg_.stride[k];
+      smg_.mmask[k] = sg_.mmask[k];
+    }
+  }
+
   const bool rows_ok = layout_ == LAYOUT_LEX && (n[0] % 4 == 0) && d <= CG_ROWS_MAXD + 2;
   const bool planes_ok = rows_ok && d == 3;
   const bool morton4_ok = layout_ == LAYOUT_MORTON && d >= 2 && N_ >= 4 && N_ % 4 == 0;
@@ -792,11 +808,43 @@ void Solver::launch_iteration()
     launch_exchange(1, false);
 }
 
+template <int LAYOUT>
+static void launch_small_d(const SmallGeom &g, const VecArgs &a, double *partB, int nB, hipStream_t s)
+{
+  const dim3 G(1), B(CG_SMALL_THREADS);
+  switch (g.d)
+  {
+  case 1: hipLaunchKernelGGL((k_small<LAYOUT, 1>), G, B, 0, s, g, a, partB, nB); break;
+  case 2: hipLaunchKernelGGL((k_small<LAYOUT, 2>), G, B, 0, s, g, a, partB, nB); break;
+  case 3: hipLaunchKernelGGL((k_small<LAYOUT, 3>), G, B, 0, s, g, a, partB, nB); break;
+  case 4: hipLaunchKernelGGL((k_small<LAYOUT, 4>), G, B, 0, s, g, a, partB, nB); break;
+  default: hipLaunchKernelGGL((k_small<LAYOUT, 0>), G, B, 0, s, g, a, partB, nB);
+  }
+}
+
+void Solver::launch_small()
+{
+  if (layout_ == LAYOUT_MORTON)
+    launch_small_d<LAYOUT_MORTON>(smg_, args(), partB_, grid_, stream_);
+  else
+    launch_small_d<LAYOUT_LEX>(smg_, args(), partB_, grid_, stream_);
+}
+
+bool Solver::small_path() const { return small_ && !linked_ && sumA_ == partA_ && sumB_ == partB_; }
+
 void Solver::iterate(int n, bool use_graph)
 {
   if (n <= 0)
     return;
   add_iterations(n);
+  if (small_path())
+  {
+    // one launch runs all n iterations (or stops at convergence) and leaves the state as n rounds
+    // of kernels A and B would
+    launch_small();
+    CHECK(hipGetLastError());
+    return;
+  }
   const int chunk = std::max(1, env_int("CG_GRAPH_ITERS", 20));
   if (!use_graph)
   {
@@ -827,6 +875,8 @@ void Solver::run(int maxit, bool use_graph, int poll)
 {
   long long left = maxit < 0 ? (1ll << 40) : maxit;
   CgState s;
+  if (small_path())
+    poll = 1 << 20; // the single-workgroup kernel stops by itself: no need to come back to the host
   while (left > 0)
   {
     const int n = (int)std::min<long long>(left, poll);

@@ -10,6 +10,7 @@
 #include "cg_links.hpp"
 #include "cg_morton.hpp"
 #include "cg_planes.hpp"
+#include "cg_small.hpp"
 
 namespace cgamd
 {
@@ -122,6 +123,10 @@ private:
   int planes_r_ = 4;
   ScalarGeom sg_{};
   int grid_ = 1, block_ = 256;
+  bool small_ = false;      // grid fits one workgroup: iterate() may run it in a single launch
+  SmallGeom smg_{};
+  void launch_small();
+  bool small_path() const;  // ... and nothing (slab neighbours, external sums, boxes) forbids it
   bool linked_ = false;
   LinkArgs links_{};
   LinkCtl *link_ctl_ = nullptr;

@@ -532,3 +532,58 @@ def test_engines_agree_on_non_cubic_grids(lib, ext):
     for engine, (xe, he) in results.items():
         assert np.allclose(he, ref_h, rtol=1e-5), (engine, he, ref_h)
         assert rel_l2(xe, ref_x) <= 1e-5, engine
+
+
+# ---- grids that fit one workgroup: whole iterations in a single launch -------------------------
+
+def _solve(lib, ext, b, plan, mode=0):
+    """plan: list of ('it', n) -> iterate(n) or ('ab', n) -> n explicit kernel A / kernel B rounds."""
+    N = b.numel()
+    s = lib.make_solver(ext, index_mode=mode)
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    s.begin(b.data_ptr(), x.data_ptr(), 1e-6, 1)
+    for what, n in plan:
+        if what == "it":
+            s.iterate(n, use_graph=True)
+        else:
+            s.add_iterations(n)
+            for _ in range(n):
+                s.kernel_A()
+                s.kernel_B()
+    iters, res, hist = s.finish(hist_len=300)
+    s.close()
+    return x.cpu().numpy(), iters, res, np.array(hist)
+
+
+@pytest.mark.parametrize("ext,mode", [([64, 64], 0), ([50, 50], 0), ([16, 16, 16], 0), ([8, 8, 8, 8], 0), ([5, 5, 5], 0),
+                                      ([4, 4, 4, 4, 4], 0), ([8191], 0), ([16, 16, 16], 2), ([64, 64], 2), ([90, 91], 0)])
+def test_single_workgroup_solver_matches_the_two_kernel_iteration(lib, monkeypatch, ext, mode):
+    """Grids of at most 8192 points run whole iterations inside one workgroup (csrc/cg_small.hpp);
+    CG_SMALL=0 sends the same solve through kernels A and B.  Same iteration count, histories and
+    solutions to rounding; and the two kinds of launch can alternate on one solver."""
+    N = int(np.prod(ext))
+    rng = np.random.default_rng(N)
+    b = torch.from_numpy(rng.random(N).astype(np.float32)).cuda()
+    monkeypatch.setenv("CG_SMALL", "0")
+    x0, it0, res0, h0 = _solve(lib, ext, b, [("it", 200)], mode)
+    monkeypatch.setenv("CG_SMALL", "1")
+    x1, it1, res1, h1 = _solve(lib, ext, b, [("it", 200)], mode)
+    x2, it2, res2, h2 = _solve(lib, ext, b, [("it", 7), ("ab", 3), ("it", 5), ("ab", 2), ("it", 183)], mode)
+    for x, it, res, h in ((x1, it1, res1, h1), (x2, it2, res2, h2)):
+        assert iters_close(it, it0), (it, it0)
+        n = min(len(h), len(h0), 40)
+        assert np.allclose(h[:n], h0[:n], rtol=1e-3)
+        assert rel_l2(x, x0) <= 1e-4
+    # alternating launch kinds changes nothing but the association of the dot products
+    assert it2 == it1 or iters_close(it2, it1)
+
+
+def test_single_workgroup_solver_pauses_and_resumes(lib):
+    """iterate(n) on a small grid stops after exactly n iterations and can be continued."""
+    ext = [32, 32]
+    N = 1024
+    b = torch.from_numpy(np.random.default_rng(5).random(N).astype(np.float32)).cuda()
+    xa, ita, _, ha = _solve(lib, ext, b, [("it", 30)])
+    xb, itb, _, hb = _solve(lib, ext, b, [("it", 10), ("it", 10), ("it", 10)])
+    assert ita == itb == 30
+    assert np.array_equal(ha, hb) and np.array_equal(xa, xb)
