@@ -426,7 +426,7 @@ void Solver::build_geometry()
 
   // small grids: whole iterations inside one workgroup (cg_small.hpp); automatic engine choice only
   small_ = desc_.engine == ENGINE_AUTO && !desc_.has_lo && !desc_.has_hi && N_ <= (size_t)CG_SMALL_MAX &&
-           d <= CG_SMALL_MAXD && env_int("CG_SMALL", 1);
+           d <= CG_SMALL_MAXD && env_int("CG_SMALL", 1) && env_int("CG_ENGINE", 0) == 0; // a forced engine is obeyed
   if (small_)
   {
     memset(&smg_, 0, sizeof(smg_));
