@@ -133,7 +133,7 @@ def cpu_baseline(ext, budget_s):
     x_port, _, done, _ = o.conjugate_gradient(b, L, d)
     dt_port = time.perf_counter() - t0
     scale = n / n_full
-    port = {"value": done / dt_port * scale, "unit": "iterations/s", "cores": 1, "kind": "port",
+    port = {"value": done / dt_port * scale, "unit": "iterations/s", "cores": 1, "kind": "port", "L": L,
             "sample": f"{done} fp64 CG iterations to 1e-6 on a {L}^{d} grid ({n} points, {dt_port:.1f} s), "
                       f"scaled by points to the {'x'.join(map(str, ext))} workload"}
     ref = orc.Reference(native=True)
@@ -149,13 +149,44 @@ def cpu_baseline(ext, budget_s):
             "port": port}
 
 
+def cpu_baseline_all_cores(ext, L):
+    """The same CPU loops spread over all cores with OpenMP (oracle/cg_oracle_omp.c) on the L^d sample
+    grid of cpu_baseline: a second, separately labelled figure.  The reference has no threading; this
+    is not the reference."""
+    import numpy as np
+    path = os.path.join(ROOT, "oracle", "libcg_oracle_omp.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    lib.orc_cg_omp.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.orc_cg_omp.restype = C.c_double
+    d = len(ext)
+    n_full = 1
+    for e in ext:
+        n_full *= e
+    n = L ** d
+    b = np.zeros(n + 1)
+    b[:n] = np.random.default_rng(1).random(n)
+    x = np.zeros(n + 1)
+    it, th = C.c_int(0), C.c_int(0)
+    t0 = time.perf_counter()
+    lib.orc_cg_omp(b, x, L, d, -1, C.byref(it), C.byref(th))
+    dt = time.perf_counter() - t0
+    return {"value": it.value / dt * n / n_full, "unit": "iterations/s", "cores": th.value, "kind": "port-omp",
+            "sample": f"{it.value} fp64 CG iterations on the {L}^{d} grid with OpenMP on {th.value} threads ({dt:.1f} s), "
+                      f"scaled by points; not the reference (which is single-threaded)"}
+
+
 def cpu_baselines_isolated(ext, budget_s):
     """Run the CPU legs in a child process: a host-side failure there (e.g. an instruction the
     box's CPU lacks) must not take the GPU result down with it."""
     import subprocess
     code = ("import json,sys; sys.path.insert(0, %r); import bench; "
-            "print(json.dumps({'cpu_baseline': bench.cpu_baseline(%r, %r), "
-            "'cpu_baseline_1d_2e20': bench.cpu_baseline_c1()}))" % (ROOT, list(ext), float(budget_s)))
+            "cb = bench.cpu_baseline(%r, %r); "
+            "L = cb.get('L') or cb.get('port', {}).get('L'); "
+            "print(json.dumps({'cpu_baseline': cb, 'cpu_baseline_all_cores': bench.cpu_baseline_all_cores(%r, L), "
+            "'cpu_baseline_1d_2e20': bench.cpu_baseline_c1()}))" % (ROOT, list(ext), float(budget_s), list(ext)))
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
         if r.returncode == 0:

@@ -191,3 +191,27 @@ def test_f32_emulation_tracks_f64(oracle):
     x32, res, iters, hist = oracle.cg_f32(g["b"].astype(np.float32), 10, 2, hist_len=200)
     assert 0 < iters <= 200 and len(hist) == iters
     assert np.all(np.abs(x32 - g["x"]) < 1e-3)  # tests.cu:466-501 acceptance
+
+
+def test_all_cores_variant_agrees_with_the_serial_oracle(oracle):
+    """oracle/cg_oracle_omp.c (the benchmark's separately labelled all-cores CPU figure) runs the same
+    loops with OpenMP reductions: same iteration count, solution equal to re-association error."""
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libcg_oracle_omp.so")
+    if not os.path.exists(path):
+        pytest.skip("all-cores variant not built")
+    lib = C.CDLL(path)
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    lib.orc_cg_omp.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.orc_cg_omp.restype = C.c_double
+    for L, d in ((50, 2), (12, 3)):
+        n = L ** d
+        b = np.zeros(n + 1)
+        b[:n] = np.random.default_rng(L).random(n)
+        x = np.zeros(n + 1)
+        it, th = C.c_int(0), C.c_int(0)
+        lib.orc_cg_omp(b, x, L, d, -1, C.byref(it), C.byref(th))
+        xs, _, its, _ = oracle.conjugate_gradient(b[:n], L, d)
+        assert abs(it.value - its) <= 1 and th.value >= 1
+        assert np.linalg.norm(x[:n] - xs) <= 1e-9 * np.linalg.norm(xs)
