@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-slab", action="store_true", help="run the multi-rank driver even with one rank")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal: host-staged)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU owns a --workload grid; strong: the --workload grid is cut into --gpus slabs")
     ap.add_argument("--comm", default="auto", help="multi-rank exchange: auto (direct xGMI boxes if they pass a "
                     "self-check, else collectives) | links | collectives")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -223,6 +225,10 @@ def main():
     pkg = load_package()
     lib = pkg.load_library()
     ext, mode = workload_extents(args.workload)
+    if args.scaling == "strong" and world > 1:
+        if ext[-1] % world:
+            raise SystemExit(f"the slowest axis ({ext[-1]}) must be divisible by --gpus {world}")
+        ext = ext[:-1] + [ext[-1] // world]
     N = 1
     for e in ext:
         N *= e
@@ -370,11 +376,12 @@ def main():
     if rank == 0:
         its = args.steps / dt
         out = {
-            "metric": "cg_iterations_per_sec", "value": round(its * world, 3),
-            "unit": "CG iterations/s per 2^%d-point slab, summed over GPUs" % (N.bit_length() - 1)
-                    if (N & (N - 1)) == 0 else "CG iterations/s per slab, summed over GPUs",
+            "metric": "cg_iterations_per_sec", "value": round(its * (world if args.scaling == "weak" else 1), 3),
+            "unit": ("CG iterations/s of the whole grid (strong scaling)" if args.scaling == "strong" else
+                     "CG iterations/s per 2^%d-point slab, summed over GPUs" % (N.bit_length() - 1)
+                     if (N & (N - 1)) == 0 else "CG iterations/s per slab, summed over GPUs"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "local_extents": ext, "index_mode": mode,
                        "points_per_gpu": N, "parallelism": parallelism, "graph": not args.no_graph,
