@@ -587,3 +587,46 @@ def test_single_workgroup_solver_pauses_and_resumes(lib):
     xb, itb, _, hb = _solve(lib, ext, b, [("it", 10), ("it", 10), ("it", 10)])
     assert ita == itb == 30
     assert np.array_equal(ha, hb) and np.array_equal(xa, xb)
+
+
+# ---- randomised shapes, error convention ------------------------------------------------------------
+
+def _random_cubic_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        d = int(rng.integers(1, 6))
+        L = int(rng.integers(2, 41))
+        if 2 <= L ** d <= 300000:
+            out.append((L, d))
+    return out
+
+
+@pytest.mark.parametrize("L,d", _random_cubic_cases(24, 2024))
+def test_stencil_bit_exact_on_random_shapes(lib, oracle, engine_env, L, d):
+    N = L ** d
+    u = np.random.default_rng(L * 100 + d).standard_normal(N).astype(np.float32)
+    want = oracle.laplace_f32(u, d, L)
+    ud = dev(u)
+    out = torch.full((N,), np.nan, dtype=torch.float32, device="cuda")
+    lib.laplace_gpu_jl(out.data_ptr(), ud.data_ptr(), 0.0, d, L, N, 0, (N + 255) // 256, 256)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("call,needle", [
+    ("lib.conjugate_gradient_gpu_ex(b.data_ptr(), x.data_ptr(), 6, 2, index_mode=2)", "Morton"),
+    ("lib.make_solver([16, 16], 0, 1, 0).bind_links(0, [1])", "rank"),
+    ("lib.make_solver([6, 6], engine=1)", "rows engine"),
+])
+def test_precondition_failures_follow_the_reference_error_convention(call, needle):
+    """Runtime and precondition failures print 'Error: file:line ... reason: ...' to stderr and exit(1)
+    (common.h:7-17); checked in a child process because the library terminates its process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import torch; from __graft_entry__ import load_package; "
+            "lib = load_package().load_library(); b = torch.ones(36, device='cuda'); x = torch.zeros(36, device='cuda'); "
+            "%s; print('survived')" % (root, call))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, (r.returncode, r.stdout[-300:], r.stderr[-300:])
+    assert "Error:" in r.stderr and needle in r.stderr and "survived" not in r.stdout
