@@ -105,6 +105,7 @@ struct RowsGeom
   // packed mode (rows shorter than a wave's 256 points): `sub` lanes hold one row, a workgroup
   // holds `cpg` columns side by side; `ncols` columns in all
   unsigned sub, cpg, ncols;
+  unsigned long long sy; // packed mode: stride of the last axis, along which packed columns march
 };
 
 struct ScalarGeom
@@ -339,9 +340,12 @@ __device__ __forceinline__ float axis_term(float up, float c, float um) { return
 // global face, the neighbour rank's data on a slab face, has_lo/has_hi).
 // D: compile-time dimension (1..3), 0 = run-time g.d (>= 4).
 // PACK (d >= 3, n0 = 16, 32, 64 or 128): a row of axis 0 occupies only n0/4 lanes, so the lanes of
-// a workgroup hold several columns (different coordinates of axes >= 2) side by side; a row
-// never crosses a wave, its two ends are grid faces, and everything that depends on the
-// column (base offset, face masks) is per lane instead of per workgroup.
+// a workgroup hold several columns side by side; a row never crosses a wave, its two ends are grid
+// faces, and everything that depends on the column (base offset, face masks) is per lane instead
+// of per workgroup.  Packed columns march along the LAST axis (g.n1 rows g.sy apart) and are
+// numbered along axes 1 .. d-2 (g.nk, g.sk): the neighbours with the longest stride then come from
+// registers, and the directly loaded ones are at most one plane of axes 0..d-2 away, where
+// neighbouring lanes and workgroups have just put them into the caches.
 
 __device__ __forceinline__ float4 sel4(bool c, float4 v)
 {
@@ -385,9 +389,12 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
   const float4 zero4 = make_float4(0, 0, 0, 0);
   const int d = D > 0 ? D : g.d;
   const long long n0 = g.n0;
+  // distance between consecutive rows of a march: packed columns march along the LAST axis
+  const long long rs = PACK ? (long long)g.sy : n0;
   const long long n1 = g.n1;
   // axis 1 is the ghosted (last) axis only in 2-D
-  const bool rowghost = GHOST && d == 2;
+  // packed columns march along the last axis, so (as in 2-D) the ghosted axis is the marching one
+  const bool rowghost = GHOST && (PACK || d == 2);
 
   for (unsigned item = blockIdx.x; item < g.nitems; item += gridDim.x)
   {
@@ -419,7 +426,7 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
       const unsigned ck = hi % nk;
       hi /= nk;
       base += (long long)ck * (long long)g.sk[k - 2];
-      const bool last = GHOST && (k == d - 1);
+      const bool last = !PACK && GHOST && (k == d - 1);
       // ghost planes exist in memory and hold zeros on a global face
       if (ck > 0 || last)
         okm |= 1u << (k - 2);
@@ -451,7 +458,7 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
         if (!ok) // a 1-D grid has a single row: nothing above or below to fetch
           return make_float4(0, 0, 0, 0);
       }
-      const float4 v = src.ld4(col0 + (ok ? yy : y0) * n0);
+      const float4 v = src.ld4(col0 + (ok ? yy : y0) * rs);
       return sel4(ok, v);
     };
     // the element just outside this wave's span of row yy (rows inside the grid only)
@@ -464,12 +471,12 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
         // ends of the whole grid
         const bool e1 = act && ((lane == 0 && (x0 > 0 || yy > 0)) || (lane == 63 && (x0 + 4 < g.n0 || yy + 1 < n1)));
         if (e1 && !(CG_DBG & 1))
-          e = src.ld1(col0 + yy * n0 + eoff);
+          e = src.ld1(col0 + yy * rs + eoff);
       }
       else
       {
         if (edge)
-          e = src.ld1(col0 + yy * n0 + eoff);
+          e = src.ld1(col0 + yy * rs + eoff);
       }
       return e;
     };
@@ -482,18 +489,18 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
     float4 xv = zero4, rv = zero4;
     if constexpr (MODE == MODE_B)
     {
-      xv = load4<NT>(a.x + col0 + y0 * n0);
-      rv = load4<false>(a.r + col0 + y0 * n0);
+      xv = load4<NT>(a.x + col0 + y0 * rs);
+      rv = load4<false>(a.r + col0 + y0 * rs);
     }
     if constexpr (MODE == MODE_A)
     {
       if (rowghost && g.has_lo && y0 == 0 && act)
-        store4<NT>(p_new + col0 - n0, pm);
+        store4<NT>(p_new + col0 - rs, pm);
     }
 
     for (long long y = y0; y < y1; y++)
     {
-      const long long idx = col0 + y * n0;
+      const long long idx = col0 + y * rs;
       // ---- prefetch for the next row -------------------------------------------------
       const long long y2 = y + 2 <= y1 ? y + 2 : y1;       // row y1 is the last one ever needed
       const float4 pnn = ldrow(y2);
@@ -503,8 +510,8 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
       {
         if (y + 1 < y1) // wave-uniform
         {
-          xn = load4<NT>(a.x + col0 + (y + 1) * n0);
-          rn = load4<false>(a.r + col0 + (y + 1) * n0);
+          xn = load4<NT>(a.x + col0 + (y + 1) * rs);
+          rn = load4<false>(a.r + col0 + (y + 1) * rs);
         }
       }
 
@@ -526,7 +533,9 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
       lv.y = 0.0f + axis_term(pc.z, pc.y, pc.x);
       lv.z = 0.0f + axis_term(pc.w, pc.z, pc.y);
       lv.w = 0.0f + axis_term(rgt, pc.w, pc.z);
-      if (d >= 2)
+      // terms are added in axis order 0, 1, ..., d-1 (conjugate-gradient_gpu.cu:172-174): the marching
+      // axis is axis 1, or the last axis for packed columns
+      if (!PACK && d >= 2)
       {
         lv.x += axis_term(pn.x, pc.x, pm.x);
         lv.y += axis_term(pn.y, pc.y, pm.y);
@@ -553,6 +562,13 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
               store4<NT>(p_new + idx + s, up);
           }
         }
+      }
+      if constexpr (PACK)
+      {
+        lv.x += axis_term(pn.x, pc.x, pm.x);
+        lv.y += axis_term(pn.y, pc.y, pm.y);
+        lv.z += axis_term(pn.z, pc.z, pm.z);
+        lv.w += axis_term(pn.w, pc.w, pm.w);
       }
       // lanes past the end of the row duplicate the last lane's data: no contribution
       if (!act)
@@ -606,7 +622,7 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
     {
       // pc now holds row y1
       if (rowghost && g.has_hi && y1 == n1 && act)
-        store4<NT>(p_new + col0 + y1 * n0, pc);
+        store4<NT>(p_new + col0 + y1 * rs, pc);
     }
   }
   if constexpr (MODE != MODE_STENCIL)

@@ -174,15 +174,29 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
     stride *= n[k];
     ncols *= n[k];
   }
-  // rows shorter than a wave: several columns side by side in one workgroup (see k_rows, PACK)
-  if (rows_packable(d, n[0]) && ncols < (1ull << 32) && env_int("CG_ROWS_PACK", 1))
+  // rows shorter than a wave: several columns side by side in one workgroup, marching along the
+  // last axis (see k_rows, PACK): columns are numbered along axes 1 .. d-2
+  if (rows_packable(d, n[0]) && env_int("CG_ROWS_PACK", 1))
   {
-    block = 256;
-    g.sub = lanes;
-    g.cpg = 256u / lanes;
-    g.ncols = (unsigned)ncols;
-    g.nxc = 1;
-    ncols = (ncols + g.cpg - 1) / g.cpg; // column groups
+    unsigned long long nc = 1, st = n[0];
+    for (int k = 1; k + 1 < d; k++)
+    {
+      g.nk[k - 1] = n[k];
+      g.sk[k - 1] = st;
+      st *= n[k];
+      nc *= n[k];
+    }
+    if (nc < (1ull << 32))
+    {
+      g.sy = st;            // stride of axis d-1
+      g.n1 = n[d - 1];
+      block = 256;
+      g.sub = lanes;
+      g.cpg = 256u / lanes;
+      g.ncols = (unsigned)nc;
+      g.nxc = 1;
+      ncols = (nc + g.cpg - 1) / g.cpg; // column groups
+    }
   }
   // scale the resident-workgroup target by the workgroup size (it is counted in 256-thread units)
   const unsigned long long target = (unsigned long long)resident_blocks() * (256 / block);
