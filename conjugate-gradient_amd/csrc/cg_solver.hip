@@ -384,10 +384,10 @@ static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
 // Which engine an automatic choice takes.  The rows and planes engines give a lane four points of
 // axis 0 and a wave 256 of them, so a short axis 0 leaves lanes idle unless the rows engine can pack
 // several rows into a wave (d >= 3 and n0 = 16, 32, 64, 128).  Measured on MI355X, kernels A / B in
-// microseconds, rows against the one-point-per-lane scalar engine: d = 4, L = 64 packed 69 / 81
-// against 124 / 103; d = 5, L = 32 packed 209 / 199 against 354 / 304; d = 6, L = 16 a tie; unpacked
-// rows of 64 points (before packing existed) lost 194 / 187 to 127 / 109.  The planes engine needs
-// 256 points per row (d = 3, L = 128: packed rows 11.7 / 12.2, planes 20.1 / 22.8).  Grids below 2^19
+// microseconds, packed rows against the one-point-per-lane scalar engine: d = 4, L = 64 56 / 71
+// against 125 / 104; d = 5, L = 32 179 / 164 against 354 / 305; d = 6, L = 16 81 / 83 against 175 / 146;
+// unpacked rows of 64 points lost 194 / 187 to the scalar engine's 127 / 109.  The planes engine needs
+// 256 points per row (d = 3, L = 128: packed rows 10.9 / 12.6, planes 16.2 / 23.4).  Grids below 2^19
 // points are launch-bound and take the scalar engine's shorter prologue.
 // CG_ENGINE = 1 (rows) | 2 (scalar) | 3 (planes) overrides the choice wherever that engine can run.
 static int choose_engine(bool rows_ok, bool planes_ok, bool morton4_ok, int d, unsigned n0, unsigned long long N)
