@@ -130,6 +130,9 @@ class SlabCG:
         """Boundary planes of r to the neighbours' ghost planes (both directions at once)."""
         if self.world == 1:
             return
+        if self._host_staged(self.r_first):
+            self._exchange_r_host_staged()
+            return
         ops = []
         if self.has_lo:
             ops.append(dist.P2POp(dist.isend, self.r_first, self._global_rank(self.rank - 1), self.group))
@@ -137,9 +140,6 @@ class SlabCG:
         if self.has_hi:
             ops.append(dist.P2POp(dist.isend, self.r_last, self._global_rank(self.rank + 1), self.group))
             ops.append(dist.P2POp(dist.irecv, self.r_ghost_hi, self._global_rank(self.rank + 1), self.group))
-        if self._host_staged(self.r_first):
-            self._exchange_r_host_staged()
-            return
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
@@ -190,7 +190,10 @@ class SlabCG:
         except Exception as e:  # noqa: BLE001 -- any failure means "use the collectives"
             ok, self.links_reason = 0, repr(e)
         gathered = [None] * self.world
-        me = (ok, socket.gethostname(), os.getpid(), torch.cuda.current_device(), handle)
+        dev_index = getattr(getattr(self.ops, "device", None), "index", None)
+        if dev_index is None:
+            dev_index = torch.cuda.current_device()
+        me = (ok, socket.gethostname(), os.getpid(), dev_index, handle)
         dist.all_gather_object(gathered, me, group=self.group)
         boxes, self._opened = [], []
         if not all(g[0] for g in gathered):
