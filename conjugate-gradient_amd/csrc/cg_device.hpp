@@ -96,6 +96,7 @@ struct RowsGeom
 {
   int d;
   unsigned n0, n1;
+  unsigned s0;     // floats between consecutive rows of axis 1: n0, or n0 rounded up to 4 (padded rows)
   unsigned nxc;    // columns per row of axis 0
   unsigned bpc;    // segments per column
   unsigned nitems; // columns * bpc
@@ -388,9 +389,11 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
   float acc = 0;
   const float4 zero4 = make_float4(0, 0, 0, 0);
   const int d = D > 0 ? D : g.d;
-  const long long n0 = g.n0;
   // distance between consecutive rows of a march: packed columns march along the LAST axis
-  const long long rs = PACK ? (long long)g.sy : n0;
+  const long long rs = PACK ? (long long)g.sy : (long long)g.s0;
+  // padded rows (n0 % 4 != 0): the last lane of a row owns fewer than four points; the others of
+  // its float4 are padding that holds zeros in r, p and x and must stay zero
+  const bool tail = (g.n0 & 3u) != 0;
   const long long n1 = g.n1;
   // axis 1 is the ghosted (last) axis only in 2-D
   // packed columns march along the last axis, so (as in 2-D) the ghosted axis is the marching one
@@ -441,7 +444,7 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
     const long long y1 = (long long)((unsigned long long)(seg + 1) * g.n1 / g.bpc);
     if (y0 >= y1)
       continue;
-    const long long col0 = base + ((PACK || act) ? x0 : g.n0 - 4u);
+    const long long col0 = base + ((PACK || act) ? x0 : ((g.n0 + 3u) & ~3u) - 4u);
     const bool el = act && lane == 0 && x0 > 0;
     const bool er = act && lane == 63 && x0 + 4 < g.n0;
     const bool edge = (el || er) && !(CG_DBG & 1);
@@ -573,6 +576,16 @@ __global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
       // lanes past the end of the row duplicate the last lane's data: no contribution
       if (!act)
         lv = zero4;
+      if (tail)
+      {
+        // A p is not zero at the padding (its left neighbour is a grid point): keep it out of r
+        if (x0 + 1 >= g.n0)
+          lv.y = 0.0f;
+        if (x0 + 2 >= g.n0)
+          lv.z = 0.0f;
+        if (x0 + 3 >= g.n0)
+          lv.w = 0.0f;
+      }
 
       if constexpr (MODE == MODE_STENCIL)
       {

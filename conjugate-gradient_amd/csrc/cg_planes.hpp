@@ -25,6 +25,7 @@ namespace cgamd
 struct PlanesGeom
 {
   unsigned n0, n1, n2;
+  unsigned s0; // floats between consecutive rows: n0, or n0 rounded up to 4 (padded rows)
   unsigned nxc, nyt, nzs; // tiles along axis 0 (256 points), axis 1 (TY rows), segments of axis 2
   unsigned nitems;
   int has_lo, has_hi;
@@ -68,8 +69,9 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
   const float alpha = coef;
   float acc = 0;
   const float4 zero4 = make_float4(0, 0, 0, 0);
-  const long long n0 = g.n0, n1 = g.n1, n2 = g.n2;
-  const long long sy = n0, sz = n0 * n1;
+  const long long n1 = g.n1, n2 = g.n2;
+  const long long sy = g.s0, sz = sy * n1;
+  const bool tail = (g.n0 & 3u) != 0; // padded rows: see k_rows
   const unsigned TY = (unsigned)nw * R;
 
   for (unsigned item = blockIdx.x; item < g.nitems; item += gridDim.x)
@@ -84,7 +86,7 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
       continue;
     const unsigned x0 = xc * 256u + (unsigned)lane * 4u;
     const bool act = x0 < g.n0;
-    const long long xcl = act ? x0 : g.n0 - 4u;
+    const long long xcl = act ? x0 : ((g.n0 + 3u) & ~3u) - 4u;
     const long long yb = (long long)yt * TY + (long long)w * R; // this wave's first row
     const bool el = act && lane == 0 && x0 > 0;
     const bool er = act && lane == 63 && x0 + 4 < g.n0;
@@ -201,6 +203,15 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
         lv.w += axis_term(pn[j].w, c.w, pm[j].w);
         if (!rowok)
           lv = zero4;
+        if (tail)
+        {
+          if (x0 + 1 >= g.n0)
+            lv.y = 0.0f;
+          if (x0 + 2 >= g.n0)
+            lv.z = 0.0f;
+          if (x0 + 3 >= g.n0)
+            lv.w = 0.0f;
+        }
 
         if constexpr (MODE == MODE_STENCIL)
         {

@@ -146,11 +146,13 @@ static int resident_blocks()
 static bool rows_packable(int d, unsigned n0) { return d >= 3 && (n0 == 16 || n0 == 32 || n0 == 64 || n0 == 128); }
 
 // columns x segments decomposition of the rows engine (see cg_device.hpp)
-static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, RowsGeom &g, int &block, int &grid)
+static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, RowsGeom &g, int &block, int &grid,
+                           unsigned s0 = 0)
 {
   memset(&g, 0, sizeof(g));
   g.d = d;
   g.n0 = n[0];
+  g.s0 = s0 ? s0 : n[0]; // row stride (padded rows: n0 rounded up to 4)
   g.n1 = d >= 2 ? n[1] : 1;
   // a long 1-D grid marches through "rows" of 1024 points (see ldedge in k_rows): consecutive rows
   // of a segment are contiguous memory, and the next row's loads are in flight while one is computed
@@ -159,14 +161,15 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
   {
     folded[1] = n[0] / 1024u;
     g.n0 = folded[0];
+    g.s0 = folded[0];
     g.n1 = folded[1];
     n = folded;
   }
-  const unsigned lanes = n[0] / 4;
+  const unsigned lanes = (n[0] + 3) / 4;
   block = (int)std::min(256u, (lanes + 63) / 64 * 64);
   block = std::max(64, std::min(256, env_int("CG_ROWS_BLOCK", block) / 64 * 64)); // k_rows is bounded to 256 threads
   g.nxc = (lanes + block - 1) / block;
-  unsigned long long ncols = g.nxc, stride = (unsigned long long)n[0] * g.n1;
+  unsigned long long ncols = g.nxc, stride = (unsigned long long)g.s0 * g.n1;
   for (int k = 2; k < d; k++)
   {
     g.nk[k - 2] = n[k];
@@ -215,10 +218,12 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
 }
 
 // tiles x segments decomposition of the planes engine (see cg_planes.hpp)
-static void make_planes_geom(const unsigned *n, int has_lo, int has_hi, PlanesGeom &g, int &block, int &grid, int &R)
+static void make_planes_geom(const unsigned *n, int has_lo, int has_hi, PlanesGeom &g, int &block, int &grid, int &R,
+                             unsigned s0 = 0)
 {
   memset(&g, 0, sizeof(g));
   g.n0 = n[0];
+  g.s0 = s0 ? s0 : n[0];
   g.n1 = n[1];
   g.n2 = n[2];
   R = env_int("CG_PLANES_R", 2) >= 4 ? 4 : 2;
@@ -305,9 +310,24 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   CG_REQUIRE(desc.index_mode >= 0 && desc.index_mode <= 2, "index_mode must be 0, 1 (lexicographic) or 2 (Morton)");
   CG_REQUIRE(!(desc.has_lo || desc.has_hi) || (layout_ == LAYOUT_LEX && desc.d >= 2),
              "slab neighbours need the lexicographic layout and d >= 2");
-  plane_ = plane_of(desc);
-  goff_ = ghost_offset_of(desc);
-  buflen_ = buffer_len_of(desc);
+  // padded rows (see cg_solver.hpp): only for stand-alone grids with the automatic engine choice,
+  // large enough to be bandwidth-bound, and not when the caller owns the buffers
+  s0_ = desc.extents[0];
+  Np_ = N_;
+  pad_ = layout_ == LAYOUT_LEX && desc.engine == ENGINE_AUTO && !desc.has_lo && !desc.has_hi && !desc.r_buf &&
+         !desc.p0_buf && !desc.p1_buf && (desc.extents[0] % 4) != 0 && desc.extents[0] >= 128 && N_ >= (1ull << 19) &&
+         desc.d <= CG_ROWS_MAXD + 2 && env_int("CG_ENGINE", 0) == 0 && env_int("CG_PAD_ROWS", 1);
+  SolverDesc sized = desc;
+  if (pad_)
+  {
+    s0_ = (desc.extents[0] + 3u) & ~3u;
+    Np_ = N_ / desc.extents[0] * s0_;
+    CG_REQUIRE(Np_ < (1ull << 32), "padded grid must have fewer than 2^32 points");
+    sized.extents[0] = s0_;
+  }
+  plane_ = plane_of(sized);
+  goff_ = ghost_offset_of(sized);
+  buflen_ = buffer_len_of(sized);
 
   if (desc.stream)
     stream_ = desc.stream;
@@ -338,6 +358,11 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   CHECK(hipMalloc((void **)&partB_own_, np * sizeof(double)));
   partA_ = partA_own_;
   partB_ = partB_own_;
+  if (pad_)
+  {
+    CHECK(hipMalloc((void **)&xpad_, Np_ * sizeof(float)));
+    CHECK(hipMemsetAsync(xpad_, 0, Np_ * sizeof(float), stream_));
+  }
   CHECK(hipMalloc((void **)&st_, sizeof(CgState)));
   CHECK(hipHostMalloc((void **)&st_host_, sizeof(CgState)));
   CHECK(hipMemsetAsync(st_, 0, sizeof(CgState), stream_));
@@ -372,6 +397,8 @@ Solver::~Solver()
   (void)hipFree(partA_own_);
   (void)hipFree(partB_own_);
   (void)hipFree(st_);
+  if (xpad_)
+    (void)hipFree(xpad_);
   if (link_ctl_)
     (void)hipFree(link_ctl_);
   (void)hipHostFree(st_host_);
@@ -439,7 +466,7 @@ void Solver::build_geometry()
   }
 
   // small grids: whole iterations inside one workgroup (cg_small.hpp); automatic engine choice only
-  small_ = desc_.engine == ENGINE_AUTO && !desc_.has_lo && !desc_.has_hi && N_ <= (size_t)CG_SMALL_MAX &&
+  small_ = !pad_ && desc_.engine == ENGINE_AUTO && !desc_.has_lo && !desc_.has_hi && N_ <= (size_t)CG_SMALL_MAX &&
            d <= CG_SMALL_MAXD && env_int("CG_SMALL", 1) && env_int("CG_ENGINE", 0) == 0; // a forced engine is obeyed
   if (small_)
   {
@@ -454,7 +481,7 @@ void Solver::build_geometry()
     }
   }
 
-  const bool rows_ok = layout_ == LAYOUT_LEX && (n[0] % 4 == 0) && d <= CG_ROWS_MAXD + 2;
+  const bool rows_ok = layout_ == LAYOUT_LEX && (n[0] % 4 == 0 || pad_) && d <= CG_ROWS_MAXD + 2;
   const bool planes_ok = rows_ok && d == 3;
   const bool morton4_ok = layout_ == LAYOUT_MORTON && d >= 2 && N_ >= 4 && N_ % 4 == 0;
   engine_ = desc_.engine == ENGINE_AUTO ? choose_engine(rows_ok, planes_ok, morton4_ok, d, n[0], N_) : desc_.engine;
@@ -467,11 +494,11 @@ void Solver::build_geometry()
 
   if (engine_ == ENGINE_ROWS)
   {
-    make_rows_geom(d, n, desc_.has_lo, desc_.has_hi, rg_, block_, grid_);
+    make_rows_geom(d, n, desc_.has_lo, desc_.has_hi, rg_, block_, grid_, s0_);
   }
   else if (engine_ == ENGINE_PLANES)
   {
-    make_planes_geom(n, desc_.has_lo, desc_.has_hi, pg_, block_, grid_, planes_r_);
+    make_planes_geom(n, desc_.has_lo, desc_.has_hi, pg_, block_, grid_, planes_r_, s0_);
   }
   else if (engine_ == ENGINE_MORTON4)
   {
@@ -672,18 +699,33 @@ static void launch_dot(const float *v, const float *w, unsigned long long n, dou
   CHECK(hipGetLastError());
 }
 
+void Solver::copy_rows(float *dst, size_t dpitch, const float *src, size_t spitch)
+{
+  const size_t n0 = desc_.extents[0];
+  CHECK(hipMemcpy2DAsync(dst, dpitch * sizeof(float), src, spitch * sizeof(float), n0 * sizeof(float), N_ / n0,
+                         hipMemcpyDeviceToDevice, stream_));
+}
+
 void Solver::begin_local(const float *b_dev, float *x_dev)
 {
   x_ = x_dev;
-  if (graph_ && graph_x_ != x_dev)
+  if (graph_ && !pad_ && graph_x_ != x_dev)
   {
     CHECK(hipGraphExecDestroy(graph_));
     graph_ = nullptr;
   }
-  CHECK(hipMemcpyAsync(r_, b_dev, N_ * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+  if (pad_)
+  {
+    x_user_ = x_dev;
+    x_ = xpad_;
+    copy_rows(r_, s0_, b_dev, desc_.extents[0]);
+    copy_rows(xpad_, s0_, x_dev, desc_.extents[0]);
+  }
+  else
+    CHECK(hipMemcpyAsync(r_, b_dev, N_ * sizeof(float), hipMemcpyDeviceToDevice, stream_));
   // p_old of iteration 0 must be finite everywhere it is read: beta = 0 then gives p = r exactly
   CHECK(hipMemsetAsync(p0_base_, 0, buflen_ * sizeof(float), stream_));
-  launch_dot(r_, r_, N_, partB_, grid_, stream_);
+  launch_dot(r_, r_, Np_, partB_, grid_, stream_); // padding holds zeros
 }
 
 void Solver::reduce_partials(int which, double *out_dev)
@@ -911,6 +953,8 @@ void Solver::read_state(CgState *host_copy)
 
 int Solver::finish(float *residue, float *hist, int hist_len)
 {
+  if (pad_ && x_user_)
+    copy_rows(x_user_, desc_.extents[0], xpad_, s0_); // the read-back below waits for it
   CgState s;
   read_state(&s);
   const int n = s.itA;

@@ -123,6 +123,15 @@ private:
   int planes_r_ = 4;
   ScalarGeom sg_{};
   int grid_ = 1, block_ = 256;
+  // padded rows: a lexicographic grid whose axis 0 is not a multiple of 4 points is kept internally
+  // with rows of s0_ = n0 rounded up to 4 floats (padding zero), so that the 16-byte engines apply;
+  // b and x are copied in at begin_local() and x is copied back by finish()
+  bool pad_ = false;
+  unsigned s0_ = 0;          // internal row stride (== extents[0] without padding)
+  size_t Np_ = 0;            // internal vector length
+  float *xpad_ = nullptr;    // internal x
+  float *x_user_ = nullptr;  // the caller's x while a padded solve is open
+  void copy_rows(float *dst, size_t dpitch, const float *src, size_t spitch); // all rows of the grid
   bool small_ = false;      // grid fits one workgroup: iterate() may run it in a single launch
   SmallGeom smg_{};
   void launch_small();

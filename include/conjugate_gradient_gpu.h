@@ -151,8 +151,12 @@ extern "C"
   void cg_solver_add_iterations(cg_solver *s, int n);
   void cg_solver_kernel_A(cg_solver *s);
   void cg_solver_kernel_B(cg_solver *s);
-  float *cg_solver_r(cg_solver *s);              /* first owned element of r */
-  float *cg_solver_p(cg_solver *s, int which);   /* first owned element of p0 / p1 */
+  /* first owned element of r / p.  (A stand-alone grid whose axis 0 is not a multiple of 4 points may be
+   * kept with rows padded to 4 floats inside the solver: cg_solver_plane() / cg_solver_buffer_len() do
+   * not describe that internal layout, and x is only complete in the caller's array after
+   * cg_solver_finish.  CG_PAD_ROWS=0 switches the padding off.) */
+  float *cg_solver_r(cg_solver *s);
+  float *cg_solver_p(cg_solver *s, int which);
 
   /* --- direct xGMI path: slab neighbours write into each other's HBM, no collective library ---
    * (no counterpart in the reference, which is single-GPU).  Every rank allocates a box,

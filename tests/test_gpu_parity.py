@@ -630,3 +630,54 @@ def test_precondition_failures_follow_the_reference_error_convention(call, needl
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1, (r.returncode, r.stdout[-300:], r.stderr[-300:])
     assert "Error:" in r.stderr and needle in r.stderr and "survived" not in r.stdout
+
+
+# ---- rows that are not a multiple of four points: padded internally ------------------------------
+
+@pytest.mark.parametrize("ext", [[1022, 700], [1001, 1001], [130, 90, 70], [258, 66, 40], [301, 33, 10, 7], [4097, 130]],
+                         ids=lambda e: "x".join(map(str, e)))
+def test_padded_rows_match_the_scalar_engine(lib, monkeypatch, ext):
+    """Large grids whose axis 0 is not a multiple of 4 are kept internally with rows padded to 4 floats
+    so that the 16-byte engines run them; CG_PAD_ROWS=0 sends them through the one-point-per-lane
+    engine.  Same iterations; x (copied back by finish) agrees to rounding and nothing outside the
+    caller's N floats is touched."""
+    N = int(np.prod(ext))
+    b = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(b.data_ptr(), N, 77)
+    outs = []
+    for pad in ("0", "1"):
+        monkeypatch.setenv("CG_PAD_ROWS", pad)
+        s = lib.make_solver(ext)
+        assert (s.engine == 2) == (pad == "0")
+        guard = torch.full((N + 64,), 123.0, dtype=torch.float32, device="cuda")
+        x = guard[:N]
+        x.zero_()
+        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.iterate(25, use_graph=True)
+        iters, res, hist = s.finish(hist_len=25)
+        assert iters == 25
+        assert torch.all(guard[N:] == 123.0)
+        outs.append((x.cpu().numpy().copy(), np.array(hist)))
+        # a second solve on the same solver, other x buffer, accumulating into a non-zero x
+        x2 = torch.ones(N, dtype=torch.float32, device="cuda")
+        s.begin(b.data_ptr(), x2.data_ptr(), 0.0, 1)
+        s.iterate(25, use_graph=True)
+        s.finish()
+        assert rel_l2(x2.cpu().numpy() - 1.0, outs[-1][0]) <= 1e-5
+        s.close()
+    assert np.allclose(outs[0][1], outs[1][1], rtol=1e-5)
+    assert rel_l2(outs[1][0], outs[0][0]) <= 1e-5
+
+
+def test_reference_entry_point_on_an_odd_large_grid(lib, oracle):
+    """conjugate_gradient_gpu_ex end to end on 1001^2 (padded rows) against the fp32 emulation."""
+    L, d = 1001, 2
+    N = L * L
+    b = np.random.default_rng(3).random(N).astype(np.float32)
+    bd = dev(b)
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    res, iters, hist = lib.conjugate_gradient_gpu_ex(bd.data_ptr(), x.data_ptr(), L, d, maxit=40, hist_len=40)
+    xe, rese, iterse, histe = oracle.cg_f32(b, L, d, maxit=40, hist_len=40)
+    assert iters == iterse == 40
+    assert np.allclose(hist, histe, rtol=1e-3)
+    assert rel_l2(x.cpu().numpy(), xe) <= 1e-4
