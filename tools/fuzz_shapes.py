@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Random grid shapes through the automatic engine choice (rows, packed rows, folded 1-D, padded
+rows, planes, single-workgroup, Morton) against the one-point-per-lane engine: 12 CG iterations,
+histories to 1e-5, solutions to 1e-5 relative L2.  usage: fuzz_shapes.py [count] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+import torch  # noqa: E402
+
+lib = load_package().load_library()
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+names = {1: "rows", 2: "scalar", 3: "planes", 4: "morton"}
+bad = 0
+for case in range(count):
+    d = int(rng.integers(1, 6))
+    while True:
+        kind = rng.integers(0, 4)
+        if kind == 0:      # powers of two
+            ext = [int(2 ** rng.integers(1, 13 if d == 1 else 9)) for _ in range(d)]
+        elif kind == 1:    # arbitrary
+            ext = [int(rng.integers(2, 3000 if d <= 2 else 300)) for _ in range(d)]
+        elif kind == 2:    # long axis 0
+            ext = [int(rng.integers(100, 5000))] + [int(rng.integers(1, 40)) for _ in range(d - 1)]
+        else:              # cubic
+            ext = [int(rng.integers(2, 200))] * d
+        N = int(np.prod(ext, dtype=np.int64))
+        if 2 <= N <= (1 << 22):
+            break
+    mode = 0
+    if kind == 0 and len(set(ext)) == 1 and d >= 2 and rng.integers(0, 2):
+        mode = 2
+    b = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(b.data_ptr(), N, 1000 + case)
+    res = []
+    for engine in (2, 0):
+        s = lib.make_solver(ext, index_mode=mode, engine=engine)
+        eng = s.engine
+        x = torch.zeros(N, dtype=torch.float32, device="cuda")
+        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.iterate(12, use_graph=bool(case & 1))
+        it, _, hist = s.finish(hist_len=12)
+        s.close()
+        res.append((x.cpu().numpy().astype(np.float64), np.array(hist), it, eng))
+    (x0, h0, i0, _), (x1, h1, i1, eng) = res
+    ok = i0 == i1 and np.allclose(h0, h1, rtol=1e-5) and np.linalg.norm(x1 - x0) <= 1e-5 * max(np.linalg.norm(x0), 1e-30)
+    bad += 0 if ok else 1
+    print(f"{case:4d} {'x'.join(map(str, ext)):>24s} mode {mode} N={N:8d} auto->{names.get(eng, eng)} {'ok' if ok else 'MISMATCH'}",
+          flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
