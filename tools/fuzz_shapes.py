@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Random grid shapes through the automatic engine choice (rows, packed rows, folded 1-D, padded
 rows, planes, single-workgroup, Morton) against the one-point-per-lane engine: 12 CG iterations,
-histories to 1e-5, solutions to 1e-5 relative L2.  usage: fuzz_shapes.py [count] [seed]"""
+histories to 1e-5, solutions to 1e-5 relative L2.  usage: fuzz_shapes.py [count] [seed]
+(FUZZ_MIN_N: smallest grid, to keep away from the launch-bound sizes that all take the scalar engine)"""
 import os
 import sys
 
@@ -18,11 +19,11 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 names = {1: "rows", 2: "scalar", 3: "planes", 4: "morton"}
 bad = 0
 for case in range(count):
-    d = int(rng.integers(1, 6))
     while True:
+        d = int(rng.integers(1, 6))
         kind = rng.integers(0, 4)
         if kind == 0:      # powers of two
-            ext = [int(2 ** rng.integers(1, 13 if d == 1 else 9)) for _ in range(d)]
+            ext = [int(2 ** rng.integers(1, 25 if d == 1 else 9)) for _ in range(d)]
         elif kind == 1:    # arbitrary
             ext = [int(rng.integers(2, 3000 if d <= 2 else 300)) for _ in range(d)]
         elif kind == 2:    # long axis 0
@@ -30,7 +31,7 @@ for case in range(count):
         else:              # cubic
             ext = [int(rng.integers(2, 200))] * d
         N = int(np.prod(ext, dtype=np.int64))
-        if 2 <= N <= (1 << 22):
+        if int(os.environ.get("FUZZ_MIN_N", 2)) <= N <= (1 << 24):
             break
     mode = 0
     if kind == 0 and len(set(ext)) == 1 and d >= 2 and rng.integers(0, 2):
