@@ -354,10 +354,11 @@ __device__ __forceinline__ float4 sel4(bool c, float4 v)
 }
 
 template <int MODE, bool GHOST, int D, int POL, bool PACK = false>
-__global__ void __launch_bounds__(256) k_rows(const RowsGeom g, const VecArgs a)
+__global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: up to 1024 lanes (512 by default)
+    const RowsGeom g, const VecArgs a)
 {
   static_assert(!PACK || D == 0 || D == 3, "packed rows exist for d >= 3 only");
-  __shared__ double sh[8];
+  __shared__ double sh[16];
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr bool NT = POL == POL_KEEP_R; // x, the stores of r and of p_new
   Src<MODE, POL> src;

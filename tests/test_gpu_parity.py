@@ -641,6 +641,7 @@ def test_padded_rows_match_the_scalar_engine(lib, monkeypatch, ext):
     so that the 16-byte engines run them; CG_PAD_ROWS=0 sends them through the one-point-per-lane
     engine.  Same iterations; x (copied back by finish) agrees to rounding and nothing outside the
     caller's N floats is touched."""
+    monkeypatch.delenv("CG_ENGINE", raising=False)   # a forced engine switches the padding off
     N = int(np.prod(ext))
     b = torch.empty(N, dtype=torch.float32, device="cuda")
     lib.c.cg_fill_uniform(b.data_ptr(), N, 77)
