@@ -83,7 +83,7 @@ def measured_traffic(workload, kernel_mode):
     try:
         ks = json.load(open(files[-1]))["kernels"]
         for name, k in ks.items():
-            if any(f"{k}<{kernel_mode}," in name for k in ("k_rows", "k_scalar", "k_planes", "k_morton4")):
+            if any(f"{k}<{kernel_mode}," in name for k in ("k_rows", "k_cols", "k_scalar", "k_planes", "k_morton4", "k_morton_tile")):
                 return k.get("traffic_bytes")
     except Exception:
         return None
@@ -263,7 +263,7 @@ def main():
         gA = BYTES_A * N / (msA * 1e-3) / 1e9
         gB = BYTES_B * N / (msB * 1e-3) / 1e9
         dom = ("B", msB, gB, BYTES_B) if msB >= msA else ("A", msA, gA, BYTES_A)
-        roof = {"bound": "hbm", "kernel": {1: "k_rows", 2: "k_scalar", 3: "k_planes", 4: "k_morton4"}[s.engine] + f"<MODE_{dom[0]}>",
+        roof = {"bound": "hbm", "kernel": s.kernel_name + f"<MODE_{dom[0]}>",
                 "achieved": round(dom[2], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(dom[2] / HBM_PEAK_GBPS, 4),
                 "traffic": measured_traffic(args.workload, 2 if dom[0] == "B" else 1),

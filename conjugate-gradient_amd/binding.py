@@ -19,7 +19,7 @@ EXPORTS = [
     "cg_allocate_field", "cg_free_field", "conjugate_gradient_gpu_ex", "preconditioned_cg_gpu",
     "cg_laplace_device", "cg_fill_uniform", "cg_u01_host", "cg_strong_scaling_events", "cg_laplace_time_events",
     "cg_solver_buffer_len", "cg_solver_ghost_offset", "cg_solver_plane", "cg_solver_create",
-    "cg_solver_destroy", "cg_solver_engine", "cg_solver_blocks", "cg_solver_begin", "cg_solver_iterate",
+    "cg_solver_destroy", "cg_solver_engine", "cg_solver_blocks", "cg_solver_kernel_name", "cg_solver_begin", "cg_solver_iterate",
     "cg_solver_finish", "cg_solver_sync", "cg_solver_time_kernels", "cg_solver_begin_local",
     "cg_solver_reduce", "cg_solver_bind_sums", "cg_solver_bind_partials", "cg_solver_init_state", "cg_solver_add_iterations",
     "cg_solver_kernel_A", "cg_solver_kernel_B", "cg_solver_r", "cg_solver_p",
@@ -106,6 +106,8 @@ class Library:
         for f in ("cg_solver_engine", "cg_solver_blocks"):
             getattr(c, f).argtypes = [vp]
             getattr(c, f).restype = i32
+        c.cg_solver_kernel_name.argtypes = [vp]
+        c.cg_solver_kernel_name.restype = C.c_char_p
         c.cg_solver_begin.argtypes = [vp, fp, fp, C.c_double, i32]
         c.cg_solver_begin.restype = None
         c.cg_solver_iterate.argtypes = [vp, i32, i32]
@@ -294,6 +296,10 @@ class Solver:
     @property
     def engine(self):
         return self.lib.c.cg_solver_engine(self.h)
+
+    @property
+    def kernel_name(self):
+        return self.lib.c.cg_solver_kernel_name(self.h).decode()
 
     @property
     def blocks(self):

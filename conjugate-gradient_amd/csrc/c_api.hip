@@ -435,6 +435,7 @@ extern "C" cg_solver *cg_solver_create(const cg_solver_desc *desc) { return new 
 extern "C" void cg_solver_destroy(cg_solver *s) { delete s; }
 extern "C" int cg_solver_engine(const cg_solver *s) { return s->impl.engine(); }
 extern "C" int cg_solver_blocks(const cg_solver *s) { return s->impl.blocks(); }
+extern "C" const char *cg_solver_kernel_name(const cg_solver *s) { return s->impl.kernel_name(); }
 
 extern "C" void cg_solver_begin(cg_solver *s, const float *b, float *x, double rel, int lagged)
 {

@@ -1,0 +1,285 @@
+// cg_cols.hpp -- the rows engine for short rows in d = 4 and 5, with R columns per lane.
+//
+// As the packed mode of k_rows (cg_device.hpp): a row of axis 0 occupies n0/4 lanes (n0 = 16 ... 128),
+// the lanes of a workgroup hold several columns side by side and march along the LAST axis with rows
+// y-1, y, y+1 in registers.  Two things differ:
+//  * every lane owns R columns that are neighbours along axis d-2, so R-1 of every R neighbour pairs
+//    of that axis are register values of the same lane and only the two columns just outside the
+//    lane's block are loaded;
+//  * the neighbours that are loaded (axes 1 .. d-3, the two block-edge columns) are fetched for row
+//    y+2 while row y is computed, in the same step in which the owners of those rows prefetch them.
+//    All uses of a cache line then fall into one step of the march.  One step of all resident
+//    workgroups moves about as many bytes as the eight L2s hold (128^4: 24 MiB against 32 MiB), so
+//    neighbours loaded at use, two steps after the owner's prefetch, came from memory again: 2.8
+//    times the ideal number of bytes left L2 in kernel A at 128^4, 1.4 times with this kernel.
+//
+// Columns are numbered along axes 1 .. d-3 (g.nk, g.sk) and then along blocks of R coordinates of
+// axis d-2 (g.nb coordinates, g.sb apart).  Terms are added in axis order 0, 1, ..., d-1
+// (conjugate-gradient_gpu.cu:172-174), so the result has the same bits as every other engine's.
+#pragma once
+#include "cg_device.hpp"
+
+namespace cgamd
+{
+
+// STREAM: everything that is touched once per kernel (x, the centre loads of r in kernel B, all
+// stores) carries the streaming hint, so that L2 and the Infinity Cache keep what neighbours re-read.
+// For grids whose vectors exceed that cache (128^4: kernel A 829 -> 781 us, B 1017 -> 946 us); on
+// smaller grids the cache serves the next kernel and plain accesses are faster (64^4: B 65 -> 72 us).
+template <int MODE, bool GHOST, int D, int R, bool STREAM>
+__global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
+{
+  static_assert(D == 4 || D == 5, "columns in blocks: d = 4 and 5");
+  static_assert(R == 1 || R == 2, "columns per lane");
+  __shared__ double sh[16];
+  const int tid = threadIdx.x;
+  Src<MODE, POL_PLAIN> src;
+  float *__restrict__ p_new = nullptr;
+  float coef = 0;
+  if constexpr (MODE == MODE_A)
+  {
+    const IterCtl c = prologue_A(a, sh);
+    if (!c.active)
+      return;
+    src.p = (c.k & 1) ? a.p1 : a.p0;
+    p_new = (c.k & 1) ? a.p0 : a.p1;
+    src.r = a.r;
+    src.beta = c.coef;
+  }
+  else if constexpr (MODE == MODE_B)
+  {
+    const IterCtl c = prologue_B(a, sh);
+    if (!c.active)
+      return;
+    src.p = (c.k & 1) ? a.p0 : a.p1;
+    coef = c.coef;
+  }
+  else
+  {
+    src.p = a.u;
+  }
+  const float alpha = coef;
+  float acc = 0;
+  const float4 zero4 = make_float4(0, 0, 0, 0);
+  constexpr int NA = D - 3; // column axes other than the blocked one
+  const long long rs = (long long)g.sy; // between consecutive rows of the march (the last axis)
+  const long long sb = (long long)g.sb; // between the R columns of a lane (axis d-2)
+  const long long n1 = g.n1;
+
+  for (unsigned item = blockIdx.x; item < g.nitems; item += gridDim.x)
+  {
+    const unsigned seg = item % g.bpc;
+    const unsigned col = item / g.bpc;
+    const unsigned c = col * g.cpg + (unsigned)tid / g.sub;
+    const bool act = c < g.ncols;
+    unsigned hi = act ? c : g.ncols - 1u; // idle lanes shadow the last column and store nothing
+    const unsigned x0 = ((unsigned)tid % g.sub) * 4u;
+    long long base = x0;
+    unsigned okm = 0, okp = 0;
+#pragma unroll
+    for (int k = 0; k < NA; k++)
+    {
+      const unsigned nk = g.nk[k];
+      const unsigned ck = hi % nk;
+      hi /= nk;
+      base += (long long)ck * (long long)g.sk[k];
+      if (ck > 0)
+        okm |= 1u << k;
+      if (ck + 1 < nk)
+        okp |= 1u << k;
+    }
+    const unsigned cb = hi * (unsigned)R; // first coordinate of the lane's block along axis d-2
+    base += (long long)cb * sb;
+    const bool has_bm = cb > 0, has_bp = cb + R < g.nb;
+    const long long y0 = (long long)((unsigned long long)seg * g.n1 / g.bpc);
+    const long long y1 = (long long)((unsigned long long)(seg + 1) * g.n1 / g.bpc);
+    if (y0 >= y1)
+      continue;
+    const bool first = x0 == 0, rightmost = x0 + 4 >= g.n0;
+
+    // stencil input of row yy of column j (a zero row outside the grid unless it is a ghost row)
+    auto ldrow = [&](int j, long long yy) -> float4 {
+      const bool ok = GHOST || (yy >= 0 && yy < n1);
+      const float4 v = src.ld4(base + j * sb + (ok ? yy : y0) * rs);
+      return sel4(ok, v);
+    };
+
+    // the directly loaded neighbours of one row
+    struct Nb
+    {
+      float4 bm, bp;
+      float4 um[NA * R], up[NA * R];
+    };
+    auto ldnb = [&](long long yy) -> Nb {
+      Nb nb;
+      const long long i = base + (yy < y1 ? yy : y1 - 1) * rs;
+      nb.bm = sel4(has_bm, src.ld4(i - (has_bm ? sb : 0)));
+      nb.bp = sel4(has_bp, src.ld4(i + (R - 1) * sb + (has_bp ? sb : 0)));
+#pragma unroll
+      for (int k = 0; k < NA; k++)
+      {
+        const long long s = (long long)g.sk[k];
+        const bool hp = (okp >> k) & 1u, hm = (okm >> k) & 1u;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+        {
+          nb.up[k * R + j] = sel4(hp, src.ld4(i + j * sb + (hp ? s : 0)));
+          nb.um[k * R + j] = sel4(hm, src.ld4(i + j * sb - (hm ? s : 0)));
+        }
+      }
+      return nb;
+    };
+
+    float4 pm[R], pc[R], pn[R], xv[R], rv[R];
+#pragma unroll
+    for (int j = 0; j < R; j++)
+    {
+      pm[j] = ldrow(j, y0 - 1);
+      pc[j] = ldrow(j, y0);
+      pn[j] = ldrow(j, y0 + 1);
+      xv[j] = zero4;
+      rv[j] = zero4;
+      if constexpr (MODE == MODE_B)
+      {
+        xv[j] = load4<STREAM>(a.x + base + j * sb + y0 * rs);
+        rv[j] = load4<STREAM>(a.r + base + j * sb + y0 * rs);
+      }
+      if constexpr (MODE == MODE_A && GHOST)
+      {
+        if (g.has_lo && y0 == 0 && act)
+          store4<STREAM>(p_new + base + j * sb - rs, pm[j]);
+      }
+    }
+
+    Nb nb0 = ldnb(y0), nb1 = ldnb(y0 + 1);
+
+    for (long long y = y0; y < y1; y++)
+    {
+      const long long idx = base + y * rs;
+      // ---- prefetch for the next rows ----------------------------------------------------
+      const long long y2 = y + 2 <= y1 ? y + 2 : y1; // row y1 is the last one ever needed
+      float4 pnn[R], xn[R], rn[R];
+#pragma unroll
+      for (int j = 0; j < R; j++)
+      {
+        pnn[j] = ldrow(j, y2);
+        xn[j] = zero4;
+        rn[j] = zero4;
+        if constexpr (MODE == MODE_B)
+        {
+          if (y + 1 < y1) // wave-uniform
+          {
+            xn[j] = load4<STREAM>(a.x + idx + j * sb + rs);
+            rn[j] = load4<STREAM>(a.r + idx + j * sb + rs);
+          }
+        }
+      }
+      const Nb nb2 = ldnb(y + 2);
+      const float4 bm = nb0.bm, bp = nb0.bp;
+
+#pragma unroll
+      for (int j = 0; j < R; j++)
+      {
+        const long long ij = idx + j * sb;
+        const float4 q = pc[j];
+        float lft = __shfl_up(q.w, 1);
+        float rgt = __shfl_down(q.x, 1);
+        if (first) // the grid face, not the previous lane's row
+          lft = 0.0f;
+        if (rightmost)
+          rgt = 0.0f;
+        float4 lv;
+        lv.x = 0.0f + axis_term(q.y, q.x, lft);
+        lv.y = 0.0f + axis_term(q.z, q.y, q.x);
+        lv.z = 0.0f + axis_term(q.w, q.z, q.y);
+        lv.w = 0.0f + axis_term(rgt, q.w, q.z);
+#pragma unroll
+        for (int k = 0; k < NA; k++)
+        {
+          const float4 up = nb0.up[k * R + j], um = nb0.um[k * R + j];
+          lv.x += axis_term(up.x, q.x, um.x);
+          lv.y += axis_term(up.y, q.y, um.y);
+          lv.z += axis_term(up.z, q.z, um.z);
+          lv.w += axis_term(up.w, q.w, um.w);
+        }
+        {
+          const float4 up = j + 1 < R ? pc[j + 1 < R ? j + 1 : j] : bp;
+          const float4 um = j > 0 ? pc[j > 0 ? j - 1 : j] : bm;
+          lv.x += axis_term(up.x, q.x, um.x);
+          lv.y += axis_term(up.y, q.y, um.y);
+          lv.z += axis_term(up.z, q.z, um.z);
+          lv.w += axis_term(up.w, q.w, um.w);
+        }
+        lv.x += axis_term(pn[j].x, q.x, pm[j].x);
+        lv.y += axis_term(pn[j].y, q.y, pm[j].y);
+        lv.z += axis_term(pn[j].z, q.z, pm[j].z);
+        lv.w += axis_term(pn[j].w, q.w, pm[j].w);
+        if (!act)
+          lv = zero4;
+
+        if constexpr (MODE == MODE_STENCIL)
+        {
+          if (act)
+            store4<false>(a.out + ij, lv);
+        }
+        else if constexpr (MODE == MODE_A)
+        {
+          if (act)
+            store4<STREAM>(p_new + ij, q);
+          acc = fmaf(q.x, lv.x, acc);
+          acc = fmaf(q.y, lv.y, acc);
+          acc = fmaf(q.z, lv.z, acc);
+          acc = fmaf(q.w, lv.w, acc);
+        }
+        else
+        {
+          float4 xo = xv[j], ro = rv[j];
+          xo.x = fmaf(alpha, q.x, xo.x);
+          xo.y = fmaf(alpha, q.y, xo.y);
+          xo.z = fmaf(alpha, q.z, xo.z);
+          xo.w = fmaf(alpha, q.w, xo.w);
+          ro.x = fmaf(-alpha, lv.x, ro.x);
+          ro.y = fmaf(-alpha, lv.y, ro.y);
+          ro.z = fmaf(-alpha, lv.z, ro.z);
+          ro.w = fmaf(-alpha, lv.w, ro.w);
+          if (act)
+          {
+            store4<STREAM>(a.x + ij, xo);
+            store4<STREAM>(a.r + ij, ro);
+          }
+          else
+            ro = zero4;
+          acc = fmaf(ro.x, ro.x, acc);
+          acc = fmaf(ro.y, ro.y, acc);
+          acc = fmaf(ro.z, ro.z, acc);
+          acc = fmaf(ro.w, ro.w, acc);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < R; j++)
+      {
+        pm[j] = pc[j];
+        pc[j] = pn[j];
+        pn[j] = pnn[j];
+        xv[j] = xn[j];
+        rv[j] = rn[j];
+      }
+      nb0 = nb1;
+      nb1 = nb2;
+    }
+    if constexpr (MODE == MODE_A && GHOST)
+    {
+      // pc now holds row y1
+      if (g.has_hi && y1 == n1 && act)
+      {
+#pragma unroll
+        for (int j = 0; j < R; j++)
+          store4<STREAM>(p_new + base + j * sb + y1 * rs, pc[j]);
+      }
+    }
+  }
+  if constexpr (MODE != MODE_STENCIL)
+    block_write_partial(acc, a.part_out, sh);
+}
+
+} // namespace cgamd

@@ -107,6 +107,11 @@ struct RowsGeom
   // holds `cpg` columns side by side; `ncols` columns in all
   unsigned sub, cpg, ncols;
   unsigned long long sy; // packed mode: stride of the last axis, along which packed columns march
+  // blocked columns (k_cols, cg_cols.hpp): a lane owns R columns that are neighbours along axis d-2
+  int R;                 // 0: one column per lane (k_rows)
+  unsigned nb;           // extent of axis d-2
+  unsigned long long sb; // its stride
+  int stream;            // k_cols: single-use traffic carries the streaming hint
 };
 
 struct ScalarGeom

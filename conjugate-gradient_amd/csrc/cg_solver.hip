@@ -201,6 +201,28 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
       g.cpg = (unsigned)block / lanes;
       g.ncols = (unsigned)nc;
       g.nxc = 1;
+      // d = 4, 5: two columns per lane, neighbours along axis d-2 (k_cols, cg_cols.hpp); that axis leaves
+      // the column numbering, which then runs over axes 1 .. d-3 and the blocks of two.  Measured,
+      // kernels A / B in us against one column per lane: 128^4 781 / 946 against 1022 / 1089,
+      // 64x64x64x512 410 / 534 against 482 / 549, 64^4 53 / 65 against 59 / 69, 64^4 x 16 1283 / 1281
+      // against 1956 / 1446; small 5-D grids and d = 3 gain nothing.  Four columns per lane spill.
+      unsigned long long N = 1;
+      for (int k = 0; k < d; k++)
+        N *= n[k];
+      const bool big = N >= (1ull << 25); // the vectors no longer fit the Infinity Cache together
+      int R = env_int("CG_COLS_R", (d == 4 || (d == 5 && big)) ? 2 : 0);
+      R = R >= 2 ? 2 : R >= 1 ? 1 : 0;
+      if (R && (d == 4 || d == 5) && n[d - 2] % (unsigned)R == 0)
+      {
+        g.R = R;
+        g.nb = n[d - 2];
+        g.sb = g.sk[d - 3];
+        g.ncols = (unsigned)(nc / R);
+        nc = g.ncols;
+        block = std::min(block, 512); // k_cols is bounded to 512 lanes
+        g.cpg = (unsigned)block / lanes;
+        g.stream = env_int("CG_COLS_STREAM", big ? 1 : 0);
+      }
       ncols = (nc + g.cpg - 1) / g.cpg; // column groups
     }
   }
@@ -516,6 +538,22 @@ void Solver::build_geometry()
   }
 }
 
+const char *Solver::kernel_name() const
+{
+  if (small_)
+    return "k_small";
+  switch (engine_)
+  {
+  case ENGINE_ROWS: return rg_.R ? "k_cols" : "k_rows";
+  case ENGINE_PLANES: return "k_planes";
+  case ENGINE_MORTON4: // the same rule as launch_morton4
+    return (mg_.N >= (unsigned long long)CG_MORTON_TILE * grid_ && mg_.N % CG_MORTON_TILE == 0 && env_int("CG_MORTON_TILED", 1))
+               ? "k_morton_tile"
+               : "k_morton4";
+  default: return "k_scalar";
+  }
+}
+
 VecArgs Solver::args() const
 {
   VecArgs a{};
@@ -534,6 +572,29 @@ VecArgs Solver::args() const
 template <int MODE, bool GHOST, int POL>
 static void launch_rows_pol(const RowsGeom &g, const VecArgs &a, int grid, int block, hipStream_t s)
 {
+  if (g.sub && g.R)
+  {
+    // blocked columns: the streaming hint is the geometry's choice (grid size) or a forced cache policy
+    const bool stream = MODE != MODE_STENCIL && (g.stream || POL == POL_KEEP_R);
+#define CG_COLS_LAUNCH(DD, RR)                                                                              \
+  do                                                                                                        \
+  {                                                                                                         \
+    if (stream)                                                                                             \
+      hipLaunchKernelGGL((k_cols<MODE, GHOST, DD, RR, MODE != MODE_STENCIL>), dim3(grid), dim3(block), 0, s, g, a); \
+    else                                                                                                    \
+      hipLaunchKernelGGL((k_cols<MODE, GHOST, DD, RR, false>), dim3(grid), dim3(block), 0, s, g, a);        \
+  } while (0)
+    if (g.d == 4 && g.R == 2)
+      CG_COLS_LAUNCH(4, 2);
+    else if (g.d == 4)
+      CG_COLS_LAUNCH(4, 1);
+    else if (g.R == 2)
+      CG_COLS_LAUNCH(5, 2);
+    else
+      CG_COLS_LAUNCH(5, 1);
+#undef CG_COLS_LAUNCH
+    return;
+  }
   if (g.sub)
   {
     if (g.d == 3)

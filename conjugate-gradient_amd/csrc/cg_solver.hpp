@@ -10,6 +10,7 @@
 #include "cg_links.hpp"
 #include "cg_morton.hpp"
 #include "cg_planes.hpp"
+#include "cg_cols.hpp"
 #include "cg_small.hpp"
 
 namespace cgamd
@@ -58,6 +59,7 @@ public:
   double *partials(int which) const { return which ? partB_ : partA_; }
   int engine() const { return engine_; }
   int blocks() const { return grid_; }
+  const char *kernel_name() const;
 
   // ---- whole-solve interface (all asynchronous on stream() until finish) -------------
   // r = b, p = 0, r.r; x is the caller's device vector of N floats and is accumulated into

@@ -126,6 +126,9 @@ extern "C"
   void cg_solver_destroy(cg_solver *s);
   int cg_solver_engine(const cg_solver *s);
   int cg_solver_blocks(const cg_solver *s);
+  /* name of the kernel template the iterations run ("k_rows", "k_cols", "k_planes", "k_morton4",
+     "k_morton_tile", "k_scalar", "k_small"), as it appears in a profiler's kernel trace; static storage */
+  const char *cg_solver_kernel_name(const cg_solver *s);
 
   /* whole solve, asynchronous until cg_solver_finish.  b, x: device pointers, N floats. */
   void cg_solver_begin(cg_solver *s, const float *b, float *x, double rel, int lagged);

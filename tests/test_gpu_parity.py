@@ -534,6 +534,39 @@ def test_engines_agree_on_non_cubic_grids(lib, ext):
         assert rel_l2(xe, ref_x) <= 1e-5, engine
 
 
+@pytest.mark.parametrize("R,stream", [(2, 0), (2, 1), (1, 1), (0, 0)])
+@pytest.mark.parametrize("ext", [[64, 6, 4, 5], [32, 3, 6, 7], [16, 5, 3, 4], [128, 9, 2, 3], [32, 4, 3, 2, 6], [16, 3, 2, 4, 5],
+                                 [16, 2, 2, 2, 2], [64, 40, 34, 9]], ids=lambda e: "x".join(map(str, e)))
+def test_blocked_columns_match_the_scalar_engine(lib, monkeypatch, ext, R, stream):
+    """4-D and 5-D grids with short rows: R columns per lane along axis d-2, neighbours fetched two
+    steps ahead, with and without the streaming hint (the automatic choice depends on the grid's
+    size), and the fall-back to one column per lane when axis d-2 has an odd extent.  The stencil must
+    have the scalar engine's bits: twelve iterations then agree to the rounding of the dot products."""
+    monkeypatch.delenv("CG_ENGINE", raising=False)
+    monkeypatch.setenv("CG_COLS_R", str(R))
+    monkeypatch.setenv("CG_COLS_STREAM", str(stream))
+    N = int(np.prod(ext))
+    b = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(b.data_ptr(), N, 33)
+    out = {}
+    for engine in (2, 1):
+        s = lib.make_solver(ext, engine=engine)
+        x = torch.zeros(N, dtype=torch.float32, device="cuda")
+        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.iterate(1, use_graph=False)
+        s.sync()
+        x1 = x.cpu().numpy().copy()
+        s.iterate(11, use_graph=True)
+        iters, res, hist = s.finish(hist_len=12)
+        assert iters == 12
+        out[engine] = (x1, x.cpu().numpy(), np.array(hist))
+        s.close()
+    # after one iteration x = alpha b: the same bits unless alpha differs in its last place
+    assert np.allclose(out[1][0], out[2][0], rtol=3e-7, atol=0)
+    assert np.allclose(out[1][2], out[2][2], rtol=1e-5)
+    assert rel_l2(out[1][1], out[2][1]) <= 1e-5
+
+
 # ---- grids that fit one workgroup: whole iterations in a single launch -------------------------
 
 def _solve(lib, ext, b, plan, mode=0):
