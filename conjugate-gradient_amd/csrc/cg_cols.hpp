@@ -65,16 +65,21 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
   const long long rs = (long long)g.sy; // between consecutive rows of the march (the last axis)
   const long long sb = (long long)g.sb; // between the R columns of a lane (axis d-2)
   const long long n1 = g.n1;
+  // padded rows (n0 % 4 != 0): the last lane of a row owns fewer than four points; the others of its
+  // float4 are padding that holds zeros in r, p and x and must stay zero
+  const bool tail = (g.n0 & 3u) != 0;
 
   for (unsigned item = blockIdx.x; item < g.nitems; item += gridDim.x)
   {
     const unsigned seg = item % g.bpc;
     const unsigned col = item / g.bpc;
     const unsigned c = col * g.cpg + (unsigned)tid / g.sub;
-    const bool act = c < g.ncols;
-    unsigned hi = act ? c : g.ncols - 1u; // idle lanes shadow the last column and store nothing
     const unsigned x0 = ((unsigned)tid % g.sub) * 4u;
-    long long base = x0;
+    // a row holds n0/4 lanes rounded up to a power of two; idle lanes (past the end of the row, past
+    // the last column) shadow a valid quad and store nothing
+    const bool act = c < g.ncols && x0 < g.n0;
+    unsigned hi = c < g.ncols ? c : g.ncols - 1u;
+    long long base = x0 < g.n0 ? x0 : ((g.n0 + 3u) & ~3u) - 4u;
     unsigned okm = 0, okp = 0;
 #pragma unroll
     for (int k = 0; k < NA; k++)
@@ -216,6 +221,16 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
         lv.w += axis_term(pn[j].w, q.w, pm[j].w);
         if (!act)
           lv = zero4;
+        if (tail)
+        {
+          // A p is not zero at the padding (its left neighbour is a grid point): keep it out of r
+          if (x0 + 1 >= g.n0)
+            lv.y = 0.0f;
+          if (x0 + 2 >= g.n0)
+            lv.z = 0.0f;
+          if (x0 + 3 >= g.n0)
+            lv.w = 0.0f;
+        }
 
         if constexpr (MODE == MODE_STENCIL)
         {

@@ -415,9 +415,10 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
     {
       const unsigned cs = (unsigned)tid / g.sub;      // column within this workgroup's group
       const unsigned c = col * g.cpg + cs;
-      act = c < g.ncols;
-      hi = act ? c : g.ncols - 1u;
       x0 = ((unsigned)tid % g.sub) * 4u;
+      // a row holds n0/4 lanes rounded up to a power of two: the lanes past its end idle
+      act = c < g.ncols && x0 < g.n0;
+      hi = c < g.ncols ? c : g.ncols - 1u;
     }
     else
     {
@@ -450,7 +451,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
     const long long y1 = (long long)((unsigned long long)(seg + 1) * g.n1 / g.bpc);
     if (y0 >= y1)
       continue;
-    const long long col0 = base + ((PACK || act) ? x0 : ((g.n0 + 3u) & ~3u) - 4u);
+    const long long col0 = base + (x0 < g.n0 ? x0 : ((g.n0 + 3u) & ~3u) - 4u);
     const bool el = act && lane == 0 && x0 > 0;
     const bool er = act && lane == 63 && x0 + 4 < g.n0;
     const bool edge = (el || er) && !(CG_DBG & 1);

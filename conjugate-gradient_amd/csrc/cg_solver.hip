@@ -142,8 +142,9 @@ static int resident_blocks()
   return std::min(cus * per_cu, max_blocks());
 }
 
-// rows shorter than a wave's 256 points that the rows engine can pack several to a wave
-static bool rows_packable(int d, unsigned n0) { return d >= 3 && (n0 == 16 || n0 == 32 || n0 == 64 || n0 == 128); }
+// rows of at most a wave's 256 points, which the rows engine packs several to a workgroup (a row takes
+// n0/4 lanes rounded up to a power of two, so at least half of the lanes work)
+static bool rows_packable(int d, unsigned n0) { return d >= 3 && n0 >= 16 && n0 <= 256; }
 
 // columns x segments decomposition of the rows engine (see cg_device.hpp)
 static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, RowsGeom &g, int &block, int &grid,
@@ -181,7 +182,10 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
   // last axis (see k_rows, PACK): columns are numbered along axes 1 .. d-2
   if (rows_packable(d, n[0]) && env_int("CG_ROWS_PACK", 1))
   {
-    unsigned long long nc = 1, st = n[0];
+    unsigned long long nc = 1, st = g.s0;
+    unsigned sub = 4;
+    while (sub < lanes)
+      sub *= 2;
     for (int k = 1; k + 1 < d; k++)
     {
       g.nk[k - 1] = n[k];
@@ -197,8 +201,8 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
       // best: 128^4 kernels A / B 1189 / 1140 us with 256 lanes, 1021 / 1087 with 512, 1289 / 1136 with
       // 1024; rows of 16 points are better off with 256 (16^6: 82 / 82 against 90 / 84)
       block = std::max(256, std::min(1024, env_int("CG_ROWS_PACK_BLOCK", n[0] >= 32 ? 512 : 256) / 256 * 256));
-      g.sub = lanes;
-      g.cpg = (unsigned)block / lanes;
+      g.sub = sub;
+      g.cpg = (unsigned)block / sub;
       g.ncols = (unsigned)nc;
       g.nxc = 1;
       // d = 4, 5: two columns per lane, neighbours along axis d-2 (k_cols, cg_cols.hpp); that axis leaves
@@ -212,6 +216,8 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
       const bool big = N >= (1ull << 25); // the vectors no longer fit the Infinity Cache together
       int R = env_int("CG_COLS_R", (d == 4 || (d == 5 && big)) ? 2 : 0);
       R = R >= 2 ? 2 : R >= 1 ? 1 : 0;
+      if (R == 2 && n[d - 2] % 2u)
+        R = env_int("CG_COLS_ODD", 1); // an odd extent leaves one column per lane (1), or k_rows (0)
       if (R && (d == 4 || d == 5) && n[d - 2] % (unsigned)R == 0)
       {
         g.R = R;
@@ -220,7 +226,7 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
         g.ncols = (unsigned)(nc / R);
         nc = g.ncols;
         block = std::min(block, 512); // k_cols is bounded to 512 lanes
-        g.cpg = (unsigned)block / lanes;
+        g.cpg = (unsigned)block / sub;
         g.stream = env_int("CG_COLS_STREAM", big ? 1 : 0);
       }
       ncols = (nc + g.cpg - 1) / g.cpg; // column groups
@@ -341,7 +347,8 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   s0_ = desc.extents[0];
   Np_ = N_;
   pad_ = layout_ == LAYOUT_LEX && desc.engine == ENGINE_AUTO && !desc.has_lo && !desc.has_hi && !desc.r_buf &&
-         !desc.p0_buf && !desc.p1_buf && (desc.extents[0] % 4) != 0 && desc.extents[0] >= 128 && N_ >= (1ull << 19) &&
+         !desc.p0_buf && !desc.p1_buf && (desc.extents[0] % 4) != 0 && (desc.extents[0] >= 128 || rows_packable(desc.d, desc.extents[0])) &&
+         N_ >= (1ull << 19) &&
          desc.d <= CG_ROWS_MAXD + 2 && env_int("CG_ENGINE", 0) == 0 && env_int("CG_PAD_ROWS", 1);
   SolverDesc sized = desc;
   if (pad_)
