@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <memory>
@@ -15,6 +16,8 @@
 #include "../../include/conjugate_gradient_gpu.hpp"
 #include "cg_solver.hpp"
 #include "hip_check.hpp"
+
+extern char **environ;
 
 using namespace cgamd;
 
@@ -95,15 +98,20 @@ unsigned long long grid_points(int L, int d)
 // benchmarks) reuse r/p buffers and the captured graph
 struct Cache
 {
-  int L = 0, d = 0, mode = -1, device = -1, forced = 0;
+  int L = 0, d = 0, mode = -1, device = -1;
+  unsigned forced = 0;
   std::unique_ptr<Solver> solver;
   Solver &get(int L_, int d_, int mode_)
   {
     const int m = mode_ == 2 ? 2 : 0;
     int dev = 0;
     CHECK(hipGetDevice(&dev));
-    const char *e = getenv("CG_ENGINE"); // part of the key: it changes which engine a new solver picks
-    const int f = (e && *e) ? atoi(e) : 0;
+    // part of the key: the CG_* environment switches change what a new solver picks (FNV-1a over them)
+    unsigned f = 2166136261u;
+    for (char **e = environ; e && *e; e++)
+      if (strncmp(*e, "CG_", 3) == 0)
+        for (const char *c = *e; *c; c++)
+          f = (f ^ (unsigned char)*c) * 16777619u;
     if (!solver || L != L_ || d != d_ || mode != m || device != dev || forced != f)
     {
       device = dev;

@@ -134,6 +134,10 @@ private:
   float *xpad_ = nullptr;    // internal x
   float *x_user_ = nullptr;  // the caller's x while a padded solve is open
   void copy_rows(float *dst, size_t dpitch, const float *src, size_t spitch); // all rows of the grid
+  // a Morton-ordered grid kept in lexicographic order inside the solver (the same begin / finish copies,
+  // as permutations)
+  bool relay_ = false;
+  void relayout(float *dst, const float *src, bool to_lex);
   bool small_ = false;      // grid fits one workgroup: iterate() may run it in a single launch
   SmallGeom smg_{};
   void launch_small();

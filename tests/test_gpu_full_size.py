@@ -97,9 +97,12 @@ def test_recurrence_residual_equals_true_residual_full_size(lib, ext):
     s.close()
 
 
-def test_morton_128_4_equals_lexicographic(lib):
+@pytest.mark.parametrize("relayout", ["0", "1"])
+def test_morton_128_4_equals_lexicographic(lib, monkeypatch, relayout):
     """The 4-D 128^4 configuration in both layouts on the same function of the coordinates:
-    identical stencil values point by point, and the same CG history for 10 iterations."""
+    identical stencil values point by point, and the same CG history for 10 iterations, with the
+    Z-curve kernels (relayout 0) and with the solver's internal lexicographic order (the default)."""
+    monkeypatch.setenv("CG_MORTON_RELAYOUT", relayout)
     L, d = 128, 4
     N = L ** d
     idx = torch.arange(N, dtype=torch.int64, device="cuda")

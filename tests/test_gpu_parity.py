@@ -403,10 +403,14 @@ def morton_perm(L, d):
     return out
 
 
-@pytest.mark.parametrize("L,d", [(32, 4), (128, 3), (1024, 2)])
-def test_morton_tiled_engine_equals_lexicographic_large(lib, oracle, L, d):
-    """The LDS-tiled Z-curve kernels against the lexicographic engines on the same data, at
-    sizes with hundreds of tiles: stencil bit-exact, 30 CG iterations to rounding."""
+@pytest.mark.parametrize("relayout", ["0", "1"])
+@pytest.mark.parametrize("L,d", [(32, 4), (128, 3), (1024, 2), (16, 5), (8, 7)])
+def test_morton_tiled_engine_equals_lexicographic_large(lib, oracle, monkeypatch, L, d, relayout):
+    """Z-curve data against the lexicographic engines on the same data, at sizes with hundreds of
+    tiles: stencil bit-exact, 30 CG iterations to rounding.  The solve runs either on the LDS-tiled
+    Z-curve kernels (relayout 0) or, the default, in lexicographic order inside the solver with b and
+    x permuted on the way in and out."""
+    monkeypatch.setenv("CG_MORTON_RELAYOUT", relayout)
     N = L ** d
     perm = morton_perm(L, d)
     if L <= 32:
@@ -428,6 +432,13 @@ def test_morton_tiled_engine_equals_lexicographic_large(lib, oracle, L, d):
     assert itl == itm == 30
     assert np.allclose(hl, hm, rtol=1e-4)
     assert rel_l2(xm.cpu().numpy()[perm], xl.cpu().numpy()) <= 1e-4
+    # x is accumulated into (conjugate-gradient_gpu.cu:327-376 never resets it): a second solve adds to the first
+    lib.conjugate_gradient_gpu_ex(ud.data_ptr(), xl.data_ptr(), L, d, index_mode=0, maxit=5)
+    lib.conjugate_gradient_gpu_ex(umd.data_ptr(), xm.data_ptr(), L, d, index_mode=2, maxit=5)
+    assert rel_l2(xm.cpu().numpy()[perm], xl.cpu().numpy()) <= 1e-4
+    s = lib.make_solver([L] * d, index_mode=2)
+    assert s.kernel_name.startswith("k_morton") == (relayout == "0"), s.kernel_name
+    s.close()
 
 
 def test_mixed_precision_3d(lib):
