@@ -157,7 +157,10 @@ extern "C"
   /* first owned element of r / p.  (A stand-alone grid whose axis 0 is not a multiple of 4 points may be
    * kept with rows padded to 4 floats inside the solver: cg_solver_plane() / cg_solver_buffer_len() do
    * not describe that internal layout, and x is only complete in the caller's array after
-   * cg_solver_finish.  CG_PAD_ROWS=0 switches the padding off.) */
+   * cg_solver_finish.  CG_PAD_ROWS=0 switches the padding off.  Likewise a Morton-ordered grid of at
+   * least 2^19 points is kept in lexicographic order inside the solver: r and p are then in that order,
+   * and x is in the caller's (Morton) order only after cg_solver_finish; CG_MORTON_RELAYOUT=0 switches
+   * that off.) */
   float *cg_solver_r(cg_solver *s);
   float *cg_solver_p(cg_solver *s, int which);
 
