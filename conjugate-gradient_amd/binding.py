@@ -17,6 +17,7 @@ EXPORTS = [
     "time_cpu_laplace", "add_jl", "laplace_gpu_jl",
     # part 2: additions
     "cg_allocate_field", "cg_free_field", "conjugate_gradient_gpu_ex", "preconditioned_cg_gpu",
+    "cg_eigen_extremes_gpu",
     "cg_laplace_device", "cg_fill_uniform", "cg_u01_host", "cg_strong_scaling_events", "cg_laplace_time_events",
     "cg_solver_buffer_len", "cg_solver_ghost_offset", "cg_solver_plane", "cg_solver_create",
     "cg_solver_destroy", "cg_solver_engine", "cg_solver_blocks", "cg_solver_kernel_name", "cg_solver_begin", "cg_solver_iterate",
@@ -85,6 +86,8 @@ class Library:
         c.conjugate_gradient_gpu_ex.restype = C.c_float
         c.preconditioned_cg_gpu.argtypes = [vp, vp, i32, i32, vp, i32, i32]
         c.preconditioned_cg_gpu.restype = i32
+        c.cg_eigen_extremes_gpu.argtypes = [i32, i32, i32, C.c_double, C.c_uint, vp, vp, vp, vp, vp]
+        c.cg_eigen_extremes_gpu.restype = i32
         c.cg_laplace_device.argtypes = [fp, fp, i32, i32, i32, vp]
         c.cg_laplace_device.restype = None
         c.cg_fill_uniform.argtypes = [fp, C.c_ulonglong, u32]
@@ -205,6 +208,15 @@ class Library:
         inner = (C.c_int * 1002)()
         outer = self.c.preconditioned_cg_gpu(_ptr(b), _ptr(x), L, d, C.cast(inner, C.c_void_p), 1002, verbose)
         return outer, [v for v in inner if v][:outer + 1] if outer else []
+
+    def eigen_extremes_gpu(self, L, d, max_steps=1000, tol=1e-7, seed=1, want_max=True, want_min=True):
+        """Returns dict(lambda_max, steps_max, lambda_min, steps_min, cg_iterations) of the L^d operator."""
+        lmax, lmin = C.c_double(0), C.c_double(0)
+        smax, smin, cgit = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.c.cg_eigen_extremes_gpu(L, d, max_steps, tol, seed, C.byref(lmax) if want_max else None, C.byref(smax),
+                                     C.byref(lmin) if want_min else None, C.byref(smin), C.byref(cgit))
+        return dict(lambda_max=lmax.value, steps_max=smax.value, lambda_min=lmin.value, steps_min=smin.value,
+                    cg_iterations=cgit.value)
 
     # ---- boxes of the direct xGMI path (all raise on a HIP error) ----------------------
     def links_alloc(self, nbytes):

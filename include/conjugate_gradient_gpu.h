@@ -86,6 +86,16 @@ extern "C"
   int preconditioned_cg_gpu(const double *b, double *x, int L, int d, int *inner_iters, int inner_len,
                             int verbose);
 
+  /* Largest and smallest eigenvalue of the L^d Laplace operator by power iteration "together with CG"
+   * (item 3 of the assignment the reference implements, tasks.md:10-24; the reference itself has no
+   * such function).  lambda_max: q <- A q / |A q|; lambda_min: inverse iteration, q <- A^-1 q / |A^-1 q|
+   * with the float GPU CG (to 1e-6) as A^-1 and the Rayleigh quotient of the iterate as the estimate.
+   * Both start from u01(seed) vectors and stop after max_steps steps or when the estimate changes by
+   * less than tol (relative).  Either result pointer may be NULL (that half is skipped); the steps_*
+   * and cg_iterations (inner CG iterations, summed) pointers may be NULL.  Returns 0. */
+  int cg_eigen_extremes_gpu(int L, int d, int max_steps, double tol, unsigned seed, double *lambda_max,
+                            int *steps_max, double *lambda_min, int *steps_min, int *cg_iterations);
+
   /* y = A u on device pointers, asynchronous on `stream` (a hipStream_t, may be NULL). */
   void cg_laplace_device(float *ddf, const float *u, int d, int L, int index_mode, void *stream);
 

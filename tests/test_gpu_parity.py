@@ -726,3 +726,21 @@ def test_reference_entry_point_on_an_odd_large_grid(lib, oracle):
     assert iters == iterse == 40
     assert np.allclose(hist, histe, rtol=1e-3)
     assert rel_l2(x.cpu().numpy(), xe) <= 1e-4
+
+
+# ---- power iteration together with CG (tasks.md:10-24; not in the reference: parity unpinned, --------
+# ---- checked against the operator's analytic spectrum) ------------------------------------------------
+
+@pytest.mark.parametrize("L,d", [(16, 2), (8, 3), (24, 1), (64, 2)])
+def test_extreme_eigenvalues_match_the_analytic_spectrum(lib, L, d):
+    """The eigenvalues of the 1-D operator are 2 - 2 cos(pi j / (L + 1)), j = 1..L; in d dimensions
+    they add up per axis.  Power iteration finds d (2 + 2 cos(pi/(L+1))), inverse iteration through the
+    float CG d (2 - 2 cos(pi/(L+1))); the condition number is their ratio."""
+    lam1 = 2.0 - 2.0 * np.cos(np.pi / (L + 1))
+    lamL = 2.0 + 2.0 * np.cos(np.pi / (L + 1))
+    r = lib.eigen_extremes_gpu(L, d, max_steps=20000, tol=1e-9)
+    assert abs(r["lambda_max"] - d * lamL) <= 2e-4 * d * lamL, r
+    assert abs(r["lambda_min"] - d * lam1) <= 1e-4 * d * lam1, r
+    assert r["steps_min"] < 60 and r["cg_iterations"] > 0
+    only_max = lib.eigen_extremes_gpu(L, d, max_steps=5, want_min=False)
+    assert only_max["steps_max"] == 5 and only_max["steps_min"] == 0 and only_max["lambda_max"] > 0
