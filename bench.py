@@ -279,7 +279,8 @@ def main():
 
         def probe(n=30):
             """A short timed run on the current transport: (seconds for n iterations, max over
-            ranks; residual history of the first three iterations)."""
+            ranks; residual history of the first three iterations; the ranks' error messages, empty
+            if none).  Every rank makes the same collective calls whatever fails on one of them."""
             x.zero_()
             barrier()
             s.begin(b, x, 0.0, 1)
@@ -291,28 +292,34 @@ def main():
             s.sync()
             barrier()
             dt = time.perf_counter() - t0
-            _, _, hist = s.finish(hist_len=3)
-            times = [None] * world
+            err, hist = "", []
+            try:
+                _, _, hist = s.finish(hist_len=3)
+            except RuntimeError as e:
+                err = f"rank {rank}: {e}"
+            seen = [None] * world
             if world > 1:
-                dist.all_gather_object(times, dt)
+                dist.all_gather_object(seen, (dt, err))
             else:
-                times = [dt]
-            return max(times), hist
+                seen = [(dt, err)]
+            return max(t for t, _ in seen), hist, "; ".join(e for _, e in seen if e)
 
         if args.comm in ("auto", "links"):
             # the direct path is used only if every rank mapped every box, the boxes reproduce the
             # collectives' residual history and ghost planes bit for bit, and it is not slower
-            t_coll, hist_c = probe()
+            t_coll, hist_c, err_c = probe()
+            if err_c:
+                raise SystemExit(f"probe over the collectives failed: {err_c}")
             if s.enable_links():
-                ok, t_link = 1, float("inf")
-                try:
-                    t_link, hist_l = probe()
-                    ok = int(len(hist_l) == 3 and all(abs(a - c) <= 1e-5 * abs(c) for a, c in zip(hist_l, hist_c)))
-                    if not ok:
-                        comm_note = f"self-check mismatch {hist_l} vs {hist_c}"
-                except RuntimeError as e:
-                    ok, comm_note = 0, str(e)
+                t_link, hist_l, err_l = probe()
+                ok = int(not err_l and len(hist_l) == 3 and
+                         all(abs(a - c) <= 1e-5 * abs(c) for a, c in zip(hist_l, hist_c)))
+                if not ok:
+                    comm_note = err_l or f"self-check mismatch {hist_l} vs {hist_c}"
+                mine = ok
                 ok = s._all_agree(ok)
+                if mine and not ok:
+                    comm_note = "self-check failed on another rank"
                 if ok and not s._all_agree(s.ghosts_match_neighbours()):
                     ok, comm_note = False, "self-check: ghost planes differ from the neighbours' boundary planes"
                 if ok and args.comm == "auto" and t_link > t_coll:

@@ -464,7 +464,7 @@ Solver::~Solver()
 
 // Which engine an automatic choice takes.  The rows and planes engines give a lane four points of
 // axis 0 and a wave 256 of them, so a short axis 0 leaves lanes idle unless the rows engine can pack
-// several rows into a wave (d >= 3 and n0 = 16, 32, 64, 128).  Measured on MI355X, kernels A / B in
+// several rows into a workgroup (d >= 3 and 16 <= n0 <= 256).  Measured on MI355X, kernels A / B in
 // microseconds, packed rows against the one-point-per-lane scalar engine: d = 4, L = 64 56 / 71
 // against 125 / 104; d = 5, L = 32 179 / 164 against 354 / 305; d = 6, L = 16 81 / 83 against 175 / 146;
 // unpacked rows of 64 points lost 194 / 187 to the scalar engine's 127 / 109.  The planes engine needs
