@@ -27,9 +27,17 @@ namespace cgamd
 // stores) carries the streaming hint, so that L2 and the Infinity Cache keep what neighbours re-read.
 // For grids whose vectors exceed that cache (128^4: kernel A 829 -> 781 us, B 1017 -> 946 us); on
 // smaller grids the cache serves the next kernel and plain accesses are faster (64^4: B 65 -> 72 us).
-template <int MODE, bool GHOST, int D, int R, bool STREAM>
+// LDS: the packed columns of a workgroup are neighbours along axis 1 (as long as they lie on one line of
+// that axis), so a lane's axis-1 neighbours are the current rows of the lanes one column slot below and
+// above: every lane puts its rows of step y into LDS (double-buffered by the step's parity, one barrier
+// per step) and only the first and last slot of the workgroup load that neighbour from memory.
+// Measured, kernels A / B in us without -> with: 128^4 780 / 946 -> 725 / 895, 64x64x64x512 388 / 578 ->
+// 360 / 463, 64^4 x 16 1271 / 1300 -> 1384 / 1156, 96^4 406 / 452 -> 500 / 449, 48^5 1229 / 1125 -> 1383 /
+// 1081: kernel B always gains, kernel A only in 4-D with rows that fill their lanes (the host chooses).
+template <int MODE, bool GHOST, int D, int R, bool STREAM, bool LDS>
 __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
 {
+  __shared__ float4 hand[LDS ? 2 * R * 512 : 1];
   static_assert(D == 4 || D == 5, "columns in blocks: d = 4 and 5");
   static_assert(R == 1 || R == 2, "columns per lane");
   __shared__ double sh[16];
@@ -74,7 +82,8 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
   {
     const unsigned seg = item % g.bpc;
     const unsigned col = item / g.bpc;
-    const unsigned c = col * g.cpg + (unsigned)tid / g.sub;
+    const unsigned cs = (unsigned)tid / g.sub; // column slot within the workgroup
+    const unsigned c = col * g.cpg + cs;
     const unsigned x0 = ((unsigned)tid % g.sub) * 4u;
     // a row holds n0/4 lanes rounded up to a power of two; idle lanes (past the end of the row, past
     // the last column) shadow a valid quad and store nothing
@@ -102,6 +111,11 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
     if (y0 >= y1)
       continue;
     const bool first = x0 == 0, rightmost = x0 + 4 >= g.n0;
+    // axis 1 (g.nk[0]): the neighbour is the next slot of this workgroup unless the slot is the first /
+    // last one; it exists at all (okm / okp) only on the same line of axis 1, where slot +-1 is column +-1
+    const bool lds_m = LDS && cs > 0, lds_p = LDS && cs + 1 < g.cpg;
+    if constexpr (LDS)
+      __syncthreads(); // the previous item's last step may still be read
 
     // stencil input of row yy of column j (a zero row outside the grid unless it is a ghost row)
     auto ldrow = [&](int j, long long yy) -> float4 {
@@ -129,8 +143,22 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
 #pragma unroll
         for (int j = 0; j < R; j++)
         {
-          nb.up[k * R + j] = sel4(hp, src.ld4(i + j * sb + (hp ? s : 0)));
-          nb.um[k * R + j] = sel4(hm, src.ld4(i + j * sb - (hm ? s : 0)));
+          if constexpr (LDS)
+          {
+            // predicated: most slots take this neighbour from LDS and skip the load
+            nb.up[k * R + j] = zero4;
+            nb.um[k * R + j] = zero4;
+            if (hp && !(k == 0 && lds_p))
+              nb.up[k * R + j] = src.ld4(i + j * sb + s);
+            if (hm && !(k == 0 && lds_m))
+              nb.um[k * R + j] = src.ld4(i + j * sb - s);
+          }
+          else
+          {
+            // never predicated (clamped address, select)
+            nb.up[k * R + j] = sel4(hp, src.ld4(i + j * sb + (hp ? s : 0)));
+            nb.um[k * R + j] = sel4(hm, src.ld4(i + j * sb - (hm ? s : 0)));
+          }
         }
       }
       return nb;
@@ -182,6 +210,25 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
       }
       const Nb nb2 = ldnb(y + 2);
       const float4 bm = nb0.bm, bp = nb0.bp;
+      if constexpr (LDS)
+      {
+        float4 *mine = hand + (size_t)(y & 1) * R * 512 + tid;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+          mine[j * 512] = pc[j];
+        __syncthreads();
+        if (NA > 0)
+        {
+#pragma unroll
+          for (int j = 0; j < R; j++)
+          {
+            if (lds_p && (okp & 1u))
+              nb0.up[j] = mine[j * 512 + (int)g.sub];
+            if (lds_m && (okm & 1u))
+              nb0.um[j] = mine[j * 512 - (int)g.sub];
+          }
+        }
+      }
 
 #pragma unroll
       for (int j = 0; j < R; j++)

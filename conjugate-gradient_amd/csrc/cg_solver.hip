@@ -230,6 +230,9 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
         block = std::min(block, 512); // k_cols is bounded to 512 lanes
         g.cpg = (unsigned)block / sub;
         g.stream = env_int("CG_COLS_STREAM", big ? 1 : 0);
+        // neighbours along axis 1 through LDS (see k_cols): kernel B always, kernel A where it measured faster
+        g.lds_b = env_int("CG_COLS_LDS_B", 1);
+        g.lds_a = env_int("CG_COLS_LDS_A", (d == 4 && sub == lanes) ? 1 : 0);
       }
       ncols = (nc + g.cpg - 1) / g.cpg; // column groups
     }
@@ -604,13 +607,21 @@ static void launch_rows_pol(const RowsGeom &g, const VecArgs &a, int grid, int b
   {
     // blocked columns: the streaming hint is the geometry's choice (grid size) or a forced cache policy
     const bool stream = MODE != MODE_STENCIL && (g.stream || POL == POL_KEEP_R);
-#define CG_COLS_LAUNCH(DD, RR)                                                                              \
+#define CG_COLS_LAUNCH_L(DD, RR, LL)                                                                        \
   do                                                                                                        \
   {                                                                                                         \
     if (stream)                                                                                             \
-      hipLaunchKernelGGL((k_cols<MODE, GHOST, DD, RR, MODE != MODE_STENCIL>), dim3(grid), dim3(block), 0, s, g, a); \
+      hipLaunchKernelGGL((k_cols<MODE, GHOST, DD, RR, MODE != MODE_STENCIL, LL>), dim3(grid), dim3(block), 0, s, g, a); \
     else                                                                                                    \
-      hipLaunchKernelGGL((k_cols<MODE, GHOST, DD, RR, false>), dim3(grid), dim3(block), 0, s, g, a);        \
+      hipLaunchKernelGGL((k_cols<MODE, GHOST, DD, RR, false, LL>), dim3(grid), dim3(block), 0, s, g, a);    \
+  } while (0)
+#define CG_COLS_LAUNCH(DD, RR)                                                                              \
+  do                                                                                                        \
+  {                                                                                                         \
+    if (MODE == MODE_B ? g.lds_b : g.lds_a)                                                                 \
+      CG_COLS_LAUNCH_L(DD, RR, true);                                                                       \
+    else                                                                                                    \
+      CG_COLS_LAUNCH_L(DD, RR, false);                                                                      \
   } while (0)
     if (g.d == 4 && g.R == 2)
       CG_COLS_LAUNCH(4, 2);
@@ -621,6 +632,7 @@ static void launch_rows_pol(const RowsGeom &g, const VecArgs &a, int grid, int b
     else
       CG_COLS_LAUNCH(5, 1);
 #undef CG_COLS_LAUNCH
+#undef CG_COLS_LAUNCH_L
     return;
   }
   if (g.sub)
