@@ -357,7 +357,7 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
          desc.d <= CG_ROWS_MAXD + 2 && env_int("CG_ENGINE", 0) == 0 && env_int("CG_PAD_ROWS", 1);
   // A Morton-ordered grid is solved in lexicographic order inside the solver: b and x are permuted in
   // at begin_local() and x is permuted back by finish(), as for padded rows.  The lexicographic engines
-  // move fewer bytes per iteration (128^4: 582 against 470 iterations/s) and the stencil's bits do not
+  // move fewer bytes per iteration (128^4: 619 against 470 iterations/s) and the stencil's bits do not
   // depend on the layout, so only the order of summation inside the dot products differs.
   relay_ = false;
   if (layout_ == LAYOUT_MORTON && desc.engine == ENGINE_AUTO && !desc.r_buf && !desc.p0_buf && !desc.p1_buf &&
