@@ -1,4 +1,4 @@
-// cg_cols.hpp -- the rows engine for short rows in d = 4 and 5, with R columns per lane.
+// cg_cols.hpp -- the rows engine for short rows in d = 3, 4 and 5, with R columns per lane.
 //
 // As the packed mode of k_rows (cg_device.hpp): a row of axis 0 occupies n0/4 lanes rounded up to a power
 // of two (n0 = 16 ... 256),
@@ -38,7 +38,7 @@ template <int MODE, bool GHOST, int D, int R, bool STREAM, bool LDS>
 __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
 {
   __shared__ float4 hand[LDS ? 2 * R * 512 : 1];
-  static_assert(D == 4 || D == 5, "columns in blocks: d = 4 and 5");
+  static_assert(D == 3 || D == 4 || D == 5, "columns in blocks: d = 3, 4 and 5");
   static_assert(R == 1 || R == 2, "columns per lane");
   __shared__ double sh[16];
   const int tid = threadIdx.x;
@@ -111,8 +111,9 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
     if (y0 >= y1)
       continue;
     const bool first = x0 == 0, rightmost = x0 + 4 >= g.n0;
-    // axis 1 (g.nk[0]): the neighbour is the next slot of this workgroup unless the slot is the first /
-    // last one; it exists at all (okm / okp) only on the same line of axis 1, where slot +-1 is column +-1
+    // axis 1 (g.nk[0]; in 3-D the blocked axis itself): the neighbour is the next slot of this workgroup
+    // unless the slot is the first / last one; it exists at all (okm / okp, has_bm / has_bp) only on the
+    // same line of axis 1, where slot +-1 is column (block) +-1
     const bool lds_m = LDS && cs > 0, lds_p = LDS && cs + 1 < g.cpg;
     if constexpr (LDS)
       __syncthreads(); // the previous item's last step may still be read
@@ -128,13 +129,26 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
     struct Nb
     {
       float4 bm, bp;
-      float4 um[NA * R], up[NA * R];
+      float4 um[NA > 0 ? NA * R : 1], up[NA > 0 ? NA * R : 1];
     };
     auto ldnb = [&](long long yy) -> Nb {
       Nb nb;
       const long long i = base + (yy < y1 ? yy : y1 - 1) * rs;
-      nb.bm = sel4(has_bm, src.ld4(i - (has_bm ? sb : 0)));
-      nb.bp = sel4(has_bp, src.ld4(i + (R - 1) * sb + (has_bp ? sb : 0)));
+      if constexpr (LDS && NA == 0)
+      {
+        // 3-D: the columns just outside the lane's block belong to the next slots of the workgroup
+        nb.bm = zero4;
+        nb.bp = zero4;
+        if (has_bm && !lds_m)
+          nb.bm = src.ld4(i - sb);
+        if (has_bp && !lds_p)
+          nb.bp = src.ld4(i + R * sb);
+      }
+      else
+      {
+        nb.bm = sel4(has_bm, src.ld4(i - (has_bm ? sb : 0)));
+        nb.bp = sel4(has_bp, src.ld4(i + (R - 1) * sb + (has_bp ? sb : 0)));
+      }
 #pragma unroll
       for (int k = 0; k < NA; k++)
       {
@@ -209,7 +223,7 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
         }
       }
       const Nb nb2 = ldnb(y + 2);
-      const float4 bm = nb0.bm, bp = nb0.bp;
+      float4 bm = nb0.bm, bp = nb0.bp;
       if constexpr (LDS)
       {
         float4 *mine = hand + (size_t)(y & 1) * R * 512 + tid;
@@ -217,7 +231,7 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
         for (int j = 0; j < R; j++)
           mine[j * 512] = pc[j];
         __syncthreads();
-        if (NA > 0)
+        if constexpr (NA > 0)
         {
 #pragma unroll
           for (int j = 0; j < R; j++)
@@ -227,6 +241,13 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
             if (lds_m && (okm & 1u))
               nb0.um[j] = mine[j * 512 - (int)g.sub];
           }
+        }
+        else
+        {
+          if (lds_m && has_bm)
+            bm = mine[(R - 1) * 512 - (int)g.sub];
+          if (lds_p && has_bp)
+            bp = mine[(int)g.sub];
         }
       }
 

@@ -207,20 +207,21 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
       g.cpg = (unsigned)block / sub;
       g.ncols = (unsigned)nc;
       g.nxc = 1;
-      // d = 4, 5: two columns per lane, neighbours along axis d-2 (k_cols, cg_cols.hpp); that axis leaves
+      // d = 3, 4, 5: two columns per lane, neighbours along axis d-2 (k_cols, cg_cols.hpp); that axis leaves
       // the column numbering, which then runs over axes 1 .. d-3 and the blocks of two.  Measured,
       // kernels A / B in us against one column per lane: 128^4 781 / 946 against 1022 / 1089,
       // 64x64x64x512 410 / 534 against 482 / 549, 64^4 53 / 65 against 59 / 69, 64^4 x 16 1283 / 1281
-      // against 1956 / 1446; small 5-D grids and d = 3 gain nothing.  Four columns per lane spill.
+      // against 1956 / 1446, 128 x 1024 x 1024 313 / 483 against 452 / 525; small 3-D and 5-D grids gain
+      // nothing.  Four columns per lane spill.
       unsigned long long N = 1;
       for (int k = 0; k < d; k++)
         N *= n[k];
       const bool big = N >= (1ull << 25); // the vectors no longer fit the Infinity Cache together
-      int R = env_int("CG_COLS_R", (d == 4 || (d == 5 && big)) ? 2 : 0);
+      int R = env_int("CG_COLS_R", (d == 4 || ((d == 3 || d == 5) && big)) ? 2 : 0);
       R = R >= 2 ? 2 : R >= 1 ? 1 : 0;
       if (R == 2 && n[d - 2] % 2u)
         R = env_int("CG_COLS_ODD", 1); // an odd extent leaves one column per lane (1), or k_rows (0)
-      if (R && (d == 4 || d == 5) && n[d - 2] % (unsigned)R == 0)
+      if (R && d <= 5 && n[d - 2] % (unsigned)R == 0)
       {
         g.R = R;
         g.nb = n[d - 2];
@@ -623,7 +624,11 @@ static void launch_rows_pol(const RowsGeom &g, const VecArgs &a, int grid, int b
     else                                                                                                    \
       CG_COLS_LAUNCH_L(DD, RR, false);                                                                      \
   } while (0)
-    if (g.d == 4 && g.R == 2)
+    if (g.d == 3 && g.R == 2)
+      CG_COLS_LAUNCH(3, 2);
+    else if (g.d == 3)
+      CG_COLS_LAUNCH(3, 1);
+    else if (g.d == 4 && g.R == 2)
       CG_COLS_LAUNCH(4, 2);
     else if (g.d == 4)
       CG_COLS_LAUNCH(4, 1);

@@ -547,9 +547,10 @@ def test_engines_agree_on_non_cubic_grids(lib, ext):
 
 @pytest.mark.parametrize("R,stream", [(2, 0), (2, 1), (1, 1), (0, 0)])
 @pytest.mark.parametrize("ext", [[64, 6, 4, 5], [32, 3, 6, 7], [16, 5, 3, 4], [128, 9, 2, 3], [32, 4, 3, 2, 6], [16, 3, 2, 4, 5],
-                                 [16, 2, 2, 2, 2], [64, 40, 34, 9]], ids=lambda e: "x".join(map(str, e)))
+                                 [16, 2, 2, 2, 2], [64, 40, 34, 9], [64, 90, 7], [128, 33, 5], [48, 200, 30], [200, 70, 3]],
+                         ids=lambda e: "x".join(map(str, e)))
 def test_blocked_columns_match_the_scalar_engine(lib, monkeypatch, ext, R, stream):
-    """4-D and 5-D grids with short rows: R columns per lane along axis d-2, neighbours fetched two
+    """3-D to 5-D grids with short rows: R columns per lane along axis d-2, neighbours fetched two
     steps ahead, with and without the streaming hint (the automatic choice depends on the grid's
     size), and the fall-back to one column per lane when axis d-2 has an odd extent.  The stencil must
     have the scalar engine's bits: twelve iterations then agree to the rounding of the dot products."""

@@ -92,7 +92,8 @@ def test_virtual_ranks_match_single_gpu_and_oracle(pkg, lib, oracle, engine_env,
     assert np.allclose(hist[:n], h1[:n], rtol=1e-5)
 
 
-@pytest.mark.parametrize("L,d,nranks,R,stream", [(16, 4, 2, 2, 1), (16, 4, 4, 1, 0), (16, 5, 2, 2, 1), (16, 5, 2, 2, 0)])
+@pytest.mark.parametrize("L,d,nranks,R,stream", [(16, 4, 2, 2, 1), (16, 4, 4, 1, 0), (16, 5, 2, 2, 1), (16, 5, 2, 2, 0),
+                                                  (32, 3, 2, 2, 1), (64, 3, 4, 1, 0)])
 def test_blocked_columns_on_slabs(pkg, lib, monkeypatch, L, d, nranks, R, stream):
     """Slabs of 4-D and 5-D grids with short rows run the columns-in-blocks kernels with ghost planes
     on the marching axis: same solution as one solver on the whole grid."""
