@@ -241,9 +241,29 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
   // scale the resident-workgroup target by the workgroup size (it is counted in 256-thread units)
   const unsigned long long target =
       block > 256 ? (unsigned long long)resident_blocks() * 256 / block : (unsigned long long)resident_blocks() * (256 / block);
-  unsigned long long bpc = ncols >= target ? 1 : target / ncols;
-  bpc = std::min<unsigned long long>(bpc, std::max(1u, g.n1 / 4)); // at least ~4 rows per segment
-  bpc = std::max<unsigned long long>(bpc, 1);
+  // Segments per column: the work items should fill the resident workgroups in whole rounds (a last
+  // round that is nearly empty, or fewer items than the chip holds, leaves CUs idle: 96^3 x 192 with 288
+  // column groups on 512 slots ran kernels A / B in 803 / 884 us, cut into 4 to 8 segments in 575 / 623),
+  // while every segment pays for two extra rows and the start of its pipeline.
+  unsigned long long bpc = 1;
+  {
+    const unsigned long long most = std::max(1u, g.n1 / 4); // at least ~4 rows per segment
+    const unsigned long long last = std::min(most, std::max<unsigned long long>(1, (4 * target + ncols - 1) / ncols));
+    double best = -1;
+    // more columns than resident workgroups: the dispatcher balances the rounds by itself (48^5, 1728
+    // column groups: cutting them in two cost 9 %)
+    for (unsigned long long c = 1; c <= (ncols >= target ? 1 : last); c++)
+    {
+      const unsigned long long n = ncols * c, rounds = (n + target - 1) / target;
+      const double fill = (double)n / (double)(rounds * target);
+      const double score = fill / (1.0 + 2.5 / (double)(g.n1 / c));
+      if (score > best * 1.0001)
+      {
+        best = score;
+        bpc = c;
+      }
+    }
+  }
   bpc = (unsigned long long)env_int("CG_ROWS_BPC", (int)bpc);
   bpc = std::max<unsigned long long>(1, std::min<unsigned long long>(bpc, g.n1));
   const unsigned long long items = ncols * bpc;
