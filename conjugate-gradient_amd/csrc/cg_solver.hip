@@ -148,6 +148,37 @@ static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
 // n0/4 lanes rounded up to a power of two, so at least half of the lanes work)
 static bool rows_packable(int d, unsigned n0) { return d >= 3 && n0 >= 16 && n0 <= 256; }
 
+// Segments per column of a march (rows engine, planes engine): the work items should fill the resident
+// workgroups in whole rounds (a last round that is nearly empty, or fewer items than the chip holds,
+// leaves CUs idle: 96^3 x 192 with 288 column groups on 512 slots ran kernels A / B in 803 / 884 us, cut
+// into 4 to 8 segments in 575 / 623), while every segment pays for two extra rows and the start of its
+// pipeline.  `length` rows (planes) along the march, at least `shortest` per segment; `cost`: what a
+// segment pays, in rows (planes) of the march.
+static unsigned long long choose_segments(unsigned long long ncols, unsigned long long target, unsigned length,
+                                          unsigned shortest, double cost)
+{
+  // more columns than resident workgroups: the dispatcher balances the rounds by itself (48^5, 1728
+  // column groups: cutting them in two cost 9 %)
+  if (ncols >= target)
+    return 1;
+  const unsigned long long most = std::max(1u, length / shortest);
+  const unsigned long long last = std::min(most, std::max<unsigned long long>(1, (4 * target + ncols - 1) / ncols));
+  unsigned long long segs = 1;
+  double best = -1;
+  for (unsigned long long c = 1; c <= last; c++)
+  {
+    const unsigned long long n = ncols * c, rounds = (n + target - 1) / target;
+    const double fill = (double)n / (double)(rounds * target);
+    const double score = fill / (1.0 + cost / (double)(length / c));
+    if (score > best * 1.0001)
+    {
+      best = score;
+      segs = c;
+    }
+  }
+  return segs;
+}
+
 // columns x segments decomposition of the rows engine (see cg_device.hpp)
 static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, RowsGeom &g, int &block, int &grid,
                            unsigned s0 = 0)
@@ -241,29 +272,7 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
   // scale the resident-workgroup target by the workgroup size (it is counted in 256-thread units)
   const unsigned long long target =
       block > 256 ? (unsigned long long)resident_blocks() * 256 / block : (unsigned long long)resident_blocks() * (256 / block);
-  // Segments per column: the work items should fill the resident workgroups in whole rounds (a last
-  // round that is nearly empty, or fewer items than the chip holds, leaves CUs idle: 96^3 x 192 with 288
-  // column groups on 512 slots ran kernels A / B in 803 / 884 us, cut into 4 to 8 segments in 575 / 623),
-  // while every segment pays for two extra rows and the start of its pipeline.
-  unsigned long long bpc = 1;
-  {
-    const unsigned long long most = std::max(1u, g.n1 / 4); // at least ~4 rows per segment
-    const unsigned long long last = std::min(most, std::max<unsigned long long>(1, (4 * target + ncols - 1) / ncols));
-    double best = -1;
-    // more columns than resident workgroups: the dispatcher balances the rounds by itself (48^5, 1728
-    // column groups: cutting them in two cost 9 %)
-    for (unsigned long long c = 1; c <= (ncols >= target ? 1 : last); c++)
-    {
-      const unsigned long long n = ncols * c, rounds = (n + target - 1) / target;
-      const double fill = (double)n / (double)(rounds * target);
-      const double score = fill / (1.0 + 2.5 / (double)(g.n1 / c));
-      if (score > best * 1.0001)
-      {
-        best = score;
-        bpc = c;
-      }
-    }
-  }
+  unsigned long long bpc = choose_segments(ncols, target, g.n1, 4, 2.5); // at least ~4 rows per segment
   bpc = (unsigned long long)env_int("CG_ROWS_BPC", (int)bpc);
   bpc = std::max<unsigned long long>(1, std::min<unsigned long long>(bpc, g.n1));
   const unsigned long long items = ncols * bpc;
@@ -300,8 +309,10 @@ static void make_planes_geom(const unsigned *n, int has_lo, int has_hi, PlanesGe
   (void)hipGetLastError();
   const unsigned long long target =
       std::min<unsigned long long>((unsigned long long)cus * std::max(1, env_int("CG_PLANES_BPCU", 2)), max_blocks());
-  unsigned long long nzs = ncols >= target ? 1 : target / ncols;
-  nzs = std::min<unsigned long long>(nzs, std::max(1u, n[2] / 8)); // keep segments >= 8 planes
+  // keep segments >= 8 planes; a segment costs more here than in the rows engine (three planes to start,
+  // the LDS hand-off): 640^3 loses 8 % in kernel A with 17 segments instead of 4, 768^3 gains 4 % with 7
+  // instead of 3
+  unsigned long long nzs = choose_segments(ncols, target, n[2], 8, 6.0);
   nzs = (unsigned long long)env_int("CG_PLANES_NZS", (int)nzs);
   nzs = std::max<unsigned long long>(1, std::min<unsigned long long>(nzs, n[2]));
   g.nzs = (unsigned)nzs;
