@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
         if constexpr (MODE == MODE_STENCIL)
         {
           if (act)
-            store4<false>(a.out + ij, lv);
+            store4<STREAM>(a.out + ij, lv);
         }
         else if constexpr (MODE == MODE_A)
         {

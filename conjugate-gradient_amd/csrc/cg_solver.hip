@@ -649,12 +649,12 @@ static void launch_rows_pol(const RowsGeom &g, const VecArgs &a, int grid, int b
   if (g.sub && g.R)
   {
     // blocked columns: the streaming hint is the geometry's choice (grid size) or a forced cache policy
-    const bool stream = MODE != MODE_STENCIL && (g.stream || POL == POL_KEEP_R);
+    const bool stream = g.stream || POL == POL_KEEP_R;
 #define CG_COLS_LAUNCH_L(DD, RR, LL)                                                                        \
   do                                                                                                        \
   {                                                                                                         \
     if (stream)                                                                                             \
-      hipLaunchKernelGGL((k_cols<MODE, GHOST, DD, RR, MODE != MODE_STENCIL, LL>), dim3(grid), dim3(block), 0, s, g, a); \
+      hipLaunchKernelGGL((k_cols<MODE, GHOST, DD, RR, true, LL>), dim3(grid), dim3(block), 0, s, g, a); \
     else                                                                                                    \
       hipLaunchKernelGGL((k_cols<MODE, GHOST, DD, RR, false, LL>), dim3(grid), dim3(block), 0, s, g, a);    \
   } while (0)
