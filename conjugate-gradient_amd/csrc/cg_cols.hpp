@@ -1,7 +1,7 @@
 // cg_cols.hpp -- the rows engine for short rows in d = 3, 4 and 5, with R columns per lane.
 //
 // As the packed mode of k_rows (cg_device.hpp): a row of axis 0 occupies n0/4 lanes rounded up to a power
-// of two (n0 = 8 ... 256),
+// of two (n0 = 4 ... 256),
 // the lanes of a workgroup hold several columns side by side and march along the LAST axis with rows
 // y-1, y, y+1 in registers.  Two things differ:
 //  * every lane owns R columns that are neighbours along axis d-2, so R-1 of every R neighbour pairs

@@ -42,7 +42,7 @@ namespace cgamd
 #endif
 
 constexpr int CG_MAXD = 32;        // scalar engine
-constexpr int CG_ROWS_MAXD = 8;    // rows engine: axes 2..9
+constexpr int CG_ROWS_MAXD = 14;   // rows engine: axes 2..15 (rows of >= 4 points and N < 2^32 allow no more)
 constexpr int CG_MAX_BLOCKS = 2048;
 constexpr int CG_HIST = 1024;      // ring of r.r values, indexed by iteration mod CG_HIST
 
@@ -346,7 +346,7 @@ __device__ __forceinline__ float axis_term(float up, float c, float um) { return
 // GHOST: the vectors own one extra hyperplane below and above the last axis (zero on a
 // global face, the neighbour rank's data on a slab face, has_lo/has_hi).
 // D: compile-time dimension (1..3), 0 = run-time g.d (>= 4).
-// PACK (d >= 3, 8 <= n0 <= 256): a row of axis 0 occupies only n0/4 lanes (rounded up to a power of
+// PACK (d >= 3, 4 <= n0 <= 256): a row of axis 0 occupies only n0/4 lanes (rounded up to a power of
 // two, the lanes past the end of the row idle), so the lanes of
 // a workgroup hold several columns side by side; a row never crosses a wave, its two ends are grid
 // faces, and everything that depends on the column (base offset, face masks) is per lane instead

@@ -145,10 +145,10 @@ static int resident_blocks()
 static bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
 
 // rows of at most a wave's 256 points, which the rows engine packs several to a workgroup (a row takes
-// n0/4 lanes rounded up to a power of two, so at least half of the lanes work).  Rows of 8 points still
-// beat the one-point-per-lane engine two to one (8^8: kernels A / B 107 / 98 against 229 / 182 us), rows
-// of 4 tie with it.
-static bool rows_packable(int d, unsigned n0) { return d >= 3 && n0 >= (unsigned)env_int("CG_PACK_MIN", 8) && n0 <= 256; }
+// n0/4 lanes rounded up to a power of two, so at least half of the lanes work).  Down to rows of 8 and
+// of 4 points (one lane per row) this beats the one-point-per-lane engine two to one (8^8: kernels A / B
+// 107 / 98 against 229 / 182 us; 4^12: 160 / 135 against 308 / 223).
+static bool rows_packable(int d, unsigned n0) { return d >= 3 && n0 >= (unsigned)env_int("CG_PACK_MIN", 4) && n0 <= 256; }
 
 // Segments per column of a march (rows engine, planes engine): the work items should fill the resident
 // workgroups in whole rounds (a last round that is nearly empty, or fewer items than the chip holds,
@@ -218,7 +218,7 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
   if (rows_packable(d, n[0]) && env_int("CG_ROWS_PACK", 1))
   {
     unsigned long long nc = 1, st = g.s0;
-    unsigned sub = 2;
+    unsigned sub = 1;
     while (sub < lanes)
       sub *= 2;
     for (int k = 1; k + 1 < d; k++)
@@ -510,7 +510,7 @@ Solver::~Solver()
 
 // Which engine an automatic choice takes.  The rows and planes engines give a lane four points of
 // axis 0 and a wave 256 of them, so a short axis 0 leaves lanes idle unless the rows engine can pack
-// several rows into a workgroup (d >= 3 and 8 <= n0 <= 256).  Measured on MI355X, kernels A / B in
+// several rows into a workgroup (d >= 3 and 4 <= n0 <= 256).  Measured on MI355X, kernels A / B in
 // microseconds, packed rows against the one-point-per-lane scalar engine: d = 4, L = 64 56 / 71
 // against 125 / 104; d = 5, L = 32 179 / 164 against 354 / 305; d = 6, L = 16 81 / 83 against 175 / 146;
 // unpacked rows of 64 points lost 194 / 187 to the scalar engine's 127 / 109.  The planes engine needs
@@ -588,7 +588,7 @@ void Solver::build_geometry()
   if (engine_ == ENGINE_MORTON4)
     CG_REQUIRE(morton4_ok, "the 4-per-lane Morton engine needs the Morton layout and d >= 2");
   if (engine_ == ENGINE_ROWS)
-    CG_REQUIRE(rows_ok, "the rows engine needs the lexicographic layout, n0 % 4 == 0 and d <= 10");
+    CG_REQUIRE(rows_ok, "the rows engine needs the lexicographic layout, n0 % 4 == 0 and d <= 16");
   if (engine_ == ENGINE_PLANES)
     CG_REQUIRE(planes_ok, "the planes engine needs a 3-D lexicographic grid with n0 % 4 == 0");
 

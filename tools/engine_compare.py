@@ -24,7 +24,7 @@ for d, L in cases:
     lib.c.cg_fill_uniform(b.data_ptr(), N, 3)
     line = f"{'x'.join(str(e) for e in ext):>18s} N=2^{N.bit_length() - 1:2d}:"
     for eng in (1, 2, 3):
-        if (eng == 3 and d != 3) or (eng != 2 and (L % 4 or d > 10)):
+        if (eng == 3 and d != 3) or (eng != 2 and (L % 4 or d > 16)):
             continue
         x = torch.zeros(N, dtype=torch.float32, device="cuda")
         s = lib.make_solver(ext, engine=eng)

@@ -3,7 +3,7 @@
 rows, planes, single-workgroup, Morton) against the one-point-per-lane engine: 12 CG iterations,
 histories to 1e-5, solutions to 1e-5 relative L2.  usage: fuzz_shapes.py [count] [seed]
 (FUZZ_MIN_N: smallest grid, to keep away from the launch-bound sizes that all take the scalar engine;
-FUZZ_PACKED=1: only grids of 3 to 6 dimensions whose rows have 8 to 256 points)"""
+FUZZ_PACKED=1: only grids of 3 to 12 dimensions whose rows have 4 to 256 points)"""
 import os
 import sys
 
@@ -32,9 +32,9 @@ for case in range(count):
         else:              # cubic
             ext = [int(rng.integers(2, 200))] * d
         if os.environ.get("FUZZ_PACKED"):  # short rows in d >= 3: packed rows, columns in blocks
-            d = int(rng.integers(3, 7))
-            n0 = int(rng.integers(2, 65)) * 4 if rng.integers(0, 4) else int(rng.integers(8, 257))
-            ext = [n0] + [int(rng.integers(1, 48)) for _ in range(d - 1)]
+            d = int(rng.integers(3, 13))
+            n0 = int(rng.integers(1, 65)) * 4 if rng.integers(0, 4) else int(rng.integers(4, 257))
+            ext = [n0] + [int(rng.integers(1, 48 if d <= 6 else 7)) for _ in range(d - 1)]
             kind = 4
         N = int(np.prod(ext, dtype=np.int64))
         if int(os.environ.get("FUZZ_MIN_N", 2)) <= N <= (1 << (26 if kind == 4 else 24)):
