@@ -390,7 +390,8 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   // 128-byte line, where that costs at most 4 % more memory (1000^3: kernels A / B 2489 / 4337 us, with
   // rows of 1024 floats 2295 / 3705 us although 2.4 % more bytes move; 500^3: 334 / 506 -> 317 / 461).
   unsigned stride0 = desc.extents[0];
-  if (stride0 % 4 != 0 && (stride0 >= 128 || rows_packable(desc.d, stride0)))
+  // (packed short rows: from 12 points on; 7^7 padded to rows of 8 lost a third to the scalar engine)
+  if (stride0 % 4 != 0 && (stride0 >= 128 || (rows_packable(desc.d, stride0) && stride0 >= 12)))
     stride0 = (stride0 + 3u) & ~3u;
   if (desc.d == 3 && desc.extents[0] >= 256 && desc.extents[0] % 32 != 0 &&
       ((desc.extents[0] + 31u) & ~31u) - desc.extents[0] <= desc.extents[0] / 25 && env_int("CG_PAD_ROWS", 1) != 4)
