@@ -481,7 +481,8 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
         // a long 1-D grid is cut into "rows" of n0 points only to march through it: the rows are
         // contiguous in memory and the ends of a row are ordinary neighbours, except at the two
         // ends of the whole grid
-        const bool e1 = act && ((lane == 0 && (x0 > 0 || yy > 0)) || (lane == 63 && (x0 + 4 < g.n0 || yy + 1 < n1)));
+        // (a row need not fill its last wave: the last lane of a row is an edge lane as well)
+        const bool e1 = act && ((lane == 0 && (x0 > 0 || yy > 0)) || (lane != 0 && rightmost && (x0 + 4 < g.n0 || yy + 1 < n1)));
         if (e1 && !(CG_DBG & 1))
           e = src.ld1(col0 + yy * rs + eoff);
       }
@@ -533,7 +534,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
       if (lane == 0)
         lft = ec;
       if (rightmost)
-        rgt = (lane == 63) ? ec : 0.0f;
+        rgt = (lane == 63 || D == 1) ? ec : 0.0f;
       if constexpr (PACK)
       {
         if (x0 == 0) // first lane of a packed row: the grid face, not the previous lane's row

@@ -190,12 +190,18 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
   g.n0 = n[0];
   g.s0 = s0 ? s0 : n[0]; // row stride (padded rows: n0 rounded up to 4)
   g.n1 = d >= 2 ? n[1] : 1;
-  // a long 1-D grid marches through "rows" of 1024 points (see ldedge in k_rows): consecutive rows
-  // of a segment are contiguous memory, and the next row's loads are in flight while one is computed
-  unsigned folded[2] = {1024u, 0u};
-  if (d == 1 && n[0] % 1024u == 0 && n[0] >= (1u << 20) && env_int("CG_ROWS_FOLD_1D", 1))
+  // a long 1-D grid marches through "rows" of up to 1024 points (see ldedge in k_rows): consecutive rows
+  // of a segment are contiguous memory, and the next row's loads are in flight while one is computed.
+  // The row length is the largest multiple of 4 from 1024 down to 512 that divides the grid (the
+  // reference's own driver solves 100000 x 312 points, main.cu:40-50: rows of 1000).
+  unsigned folded[2] = {0u, 0u};
+  if (d == 1 && n[0] >= (1u << 20) && env_int("CG_ROWS_FOLD_1D", 1))
+    for (unsigned w = 1024u; w >= 512u && !folded[0]; w -= 4u)
+      if (n[0] % w == 0)
+        folded[0] = w;
+  if (folded[0])
   {
-    folded[1] = n[0] / 1024u;
+    folded[1] = n[0] / folded[0];
     g.n0 = folded[0];
     g.s0 = folded[0];
     g.n1 = folded[1];

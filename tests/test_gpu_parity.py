@@ -74,7 +74,7 @@ def test_inner_product_host_pointer(lib):
 
 # ---- stencil ---------------------------------------------------------------------------
 
-STENCIL_CASES = [(1000, 1), (1024, 1), (4, 1), (10, 2), (5, 3), (64, 2), (256, 2), (12, 3), (16, 3), (32, 3),
+STENCIL_CASES = [(1000, 1), (1024, 1), (4, 1), (1000 * 1100, 1), (312 * 4000, 1), (10, 2), (5, 3), (64, 2), (256, 2), (12, 3), (16, 3), (32, 3),
                  (8, 4), (6, 4), (4, 5), (2, 10), (260, 2), (100, 3), (16, 4), (64, 3), (128, 3), (16, 5),
                  (1 << 20, 1), (3 << 20, 1)]
 
@@ -182,11 +182,12 @@ def test_engines_agree_with_emulation(lib, oracle, L, d, engine):
     s.close()
 
 
-def test_long_1d_grid_marches_in_rows(lib, oracle):
-    """1-D grids of 2^20 points and more are cut into contiguous 1024-point rows by the rows engine:
-    same stencil bits as the oracle (in the stencil cases above) and the same CG as the
-    one-point-per-lane engine."""
-    N = 3 << 20
+@pytest.mark.parametrize("N", [3 << 20, 1000 * 1100, 1_048_580, 312 * 4000, 516 * 2100])
+def test_long_1d_grid_marches_in_rows(lib, oracle, N):
+    """1-D grids of 2^20 points and more are cut into contiguous rows by the rows engine (the largest
+    multiple of 4 from 1024 down to 512 that divides N: 1024, 1000, none for 4 x 262145, 960, 1008; the
+    reference's own driver solves 100000 x 312 points, main.cu:40-50): same stencil bits as the oracle
+    (in the stencil cases above) and the same CG as the one-point-per-lane engine."""
     b = np.random.default_rng(4).random(N).astype(np.float32)
     bd = dev(b)
     outs = []
