@@ -96,6 +96,17 @@ extern "C"
   int cg_eigen_extremes_gpu(int L, int d, int max_steps, double tol, unsigned seed, double *lambda_max,
                             int *steps_max, double *lambda_min, int *steps_min, int *cg_iterations);
 
+  /* Two-grid correction scheme (the "Multigrid" item of the same assignment, tasks.md:32-36; no such
+   * function in the reference): u <- TG(u) until |f - A u| <= rel * |f| or max_cycles cycles.  Per cycle:
+   * nu1 damped-Jacobi steps u += omega/(2d) (f - A u), full-weighting restriction of the residual to the
+   * grid of Lc = (L-1)/2 points per axis, coarse solve A_c e_c = 4 R r by the float GPU CG (to coarse_rel,
+   * relative to its right-hand side), d-linear prolongation, nu2 Jacobi steps.  L must be odd, d <= 8;
+   * omega <= 0 selects 2d/(2d+1).  f, u: device pointers, N floats; u is the initial guess and the result.
+   * hist (hist_len floats, may be NULL) receives |f - A u| before the first and after every cycle;
+   * coarse_iterations (may be NULL) the CG iterations of all coarse solves.  Returns the cycles done. */
+  int cg_two_grid_gpu(const float *f, float *u, int L, int d, int nu1, int nu2, double omega, int max_cycles,
+                      double rel, double coarse_rel, float *hist, int hist_len, int *coarse_iterations);
+
   /* y = A u on device pointers, asynchronous on `stream` (a hipStream_t, may be NULL). */
   void cg_laplace_device(float *ddf, const float *u, int d, int L, int index_mode, void *stream);
 

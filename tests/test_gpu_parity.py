@@ -750,3 +750,71 @@ def test_extreme_eigenvalues_match_the_analytic_spectrum(lib, L, d):
     assert r["steps_min"] < 60 and r["cg_iterations"] > 0
     only_max = lib.eigen_extremes_gpu(L, d, max_steps=5, want_min=False)
     assert only_max["steps_max"] == 5 and only_max["steps_min"] == 0 and only_max["lambda_max"] > 0
+
+
+# ---- two-grid correction scheme (tasks.md:32-36; not in the reference: parity unpinned, checked --------
+# ---- through its textbook properties and against the CG solution) --------------------------------------
+
+def _prolong_numpy(ec, Lc, d):
+    """d-linear interpolation from Lc^d to (2 Lc + 1)^d, zero boundary, axis 0 fastest."""
+    L = 2 * Lc + 1
+    e = ec.reshape((Lc,) * d)          # numpy axis order is reversed, the operator is symmetric in the axes
+    for ax in range(d):
+        shape = list(e.shape)
+        shape[ax] = L
+        out = np.zeros(shape, dtype=np.float64)
+        idx = [slice(None)] * d
+        idx[ax] = slice(1, L, 2)
+        out[tuple(idx)] = e
+        lo, hi = [slice(None)] * d, [slice(None)] * d
+        lo[ax], hi[ax] = slice(0, L - 1, 2), slice(2, L + 1, 2)
+        out[tuple(lo)] += 0.5 * e
+        out[tuple(hi)] += 0.5 * e
+        e = out
+    return e.reshape(-1)
+
+
+@pytest.mark.parametrize("L,d", [(63, 2), (31, 3), (255, 1), (15, 4), (127, 2)])
+def test_two_grid_cycles_contract_the_residual(lib, oracle, L, d):
+    """Damped Jacobi (2+2 steps) with an accurate coarse solve contracts the residual by a factor that
+    does not depend on the grid size (textbook: about 0.1 to 0.2 in 2-D); the converged solution is the
+    CG solution."""
+    N = L ** d
+    rng = np.random.default_rng(L * d)
+    xt = rng.random(N).astype(np.float32)
+    f = oracle.laplace_f32(xt, d, L)
+    fd = dev(f)
+    u = torch.zeros(N, dtype=torch.float32, device="cuda")
+    cycles, hist, inner = lib.two_grid_gpu(fd.data_ptr(), u.data_ptr(), L, d, max_cycles=25, rel=1e-5)
+    assert 2 <= cycles < 25 and inner > 0
+    factors = [hist[k + 1] / hist[k] for k in range(min(cycles, 5))]
+    assert max(factors) < 0.35, factors
+    assert hist[cycles] <= 1e-5 * np.linalg.norm(f) * 1.01
+    assert np.all(np.abs(u.cpu().numpy() - xt) < 1e-3)
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    lib.conjugate_gradient_gpu_ex(fd.data_ptr(), x.data_ptr(), L, d, maxit=5000, rel=1e-6, lagged=0)
+    assert rel_l2(u.cpu().numpy(), x.cpu().numpy()) <= 1e-4
+
+
+@pytest.mark.parametrize("Lc,d", [(7, 1), (5, 2), (3, 3)])
+def test_two_grid_transfer_operators(lib, Lc, d):
+    """With no smoothing and the coarse solve switched off by a huge tolerance (e_c = 0) a cycle changes
+    nothing; with f = A (P e_c) for a random coarse vector and an exact coarse solve, one cycle of pure
+    coarse correction must return P e_c: this pins prolongation (against numpy), restriction (its
+    transpose, through the Galerkin-like identity below) and the factor 4."""
+    L = 2 * Lc + 1
+    N, Nc = L ** d, Lc ** d
+    rng = np.random.default_rng(Lc + d)
+    ec = rng.random(Nc)
+    pe = _prolong_numpy(ec, Lc, d).astype(np.float32)
+    ped = dev(pe)
+    f = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.laplace_gpu_jl(f.data_ptr(), ped.data_ptr(), 0.0, d, L, N, 0, (N + 255) // 256, 256)
+    u = torch.zeros(N, dtype=torch.float32, device="cuda")
+    cycles, hist, inner = lib.two_grid_gpu(f.data_ptr(), u.data_ptr(), L, d, nu1=0, nu2=0, max_cycles=1, rel=0.0, coarse_rel=1e9)
+    assert cycles == 1 and torch.all(u == 0)          # coarse solve returned 0: nothing prolongated
+    # 1-D: R A P = A_c / 4 exactly (Galerkin), so the coarse problem A_c e = 4 R A P e_c has the solution e_c
+    if d == 1:
+        cycles, hist, inner = lib.two_grid_gpu(f.data_ptr(), u.data_ptr(), L, d, nu1=0, nu2=0, max_cycles=1, rel=0.0, coarse_rel=1e-7)
+        assert rel_l2(u.cpu().numpy(), pe) <= 1e-4
+        assert hist[1] <= 1e-3 * hist[0]
