@@ -144,80 +144,202 @@ __global__ void __launch_bounds__(256) k_tg_prolong_add(float *__restrict__ u, c
 
 using namespace cgamd;
 
-extern "C" int cg_two_grid_gpu(const float *f, float *u, int L, int d, int nu1, int nu2, double omega, int max_cycles,
-                               double rel, double coarse_rel, float *hist, int hist_len, int *coarse_iterations)
+namespace
 {
-  CG_REQUIRE(d >= 1 && d <= 8, "the two-grid scheme is built for 1 <= d <= 8");
-  CG_REQUIRE(L >= 3 && (L & 1), "the two-grid scheme needs an odd number of points per axis, L = 2 Lc + 1 >= 3");
-  CG_REQUIRE(nu1 >= 0 && nu2 >= 0 && max_cycles >= 0, "smoothing steps and cycles must not be negative");
-  const unsigned Lc = (unsigned)(L - 1) / 2;
-  unsigned long long N = 1, Nc = 1;
-  for (int k = 0; k < d; k++)
+
+// x += a p ; r -= a q
+__global__ void __launch_bounds__(256) k_tg_update(float *__restrict__ x, float *__restrict__ r, const float *__restrict__ p,
+                                                   const float *__restrict__ q, float a, unsigned long long n)
+{
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
   {
-    N *= (unsigned)L;
-    Nc *= Lc;
+    x[i] = fmaf(a, p[i], x[i]);
+    r[i] = fmaf(-a, q[i], r[i]);
   }
-  CG_REQUIRE(N < (1ull << 31), "grid must fit an int, as in the reference");
-  if (omega <= 0)
-    omega = 2.0 * d / (2.0 * d + 1.0); // the damping that smooths the upper half of the spectrum best
-  const float w = (float)(omega / (2.0 * d));
+}
 
-  SolverDesc desc;
-  desc.d = d;
-  for (int k = 0; k < d; k++)
-    desc.extents[k] = Lc;
-  Solver coarse(desc);
-  hipStream_t s = coarse.stream();
-  float *Au, *r, *rc, *ec;
-  CHECK(hipMalloc((void **)&Au, N * sizeof(float)));
-  CHECK(hipMalloc((void **)&r, N * sizeof(float)));
-  CHECK(hipMalloc((void **)&rc, Nc * sizeof(float)));
-  CHECK(hipMalloc((void **)&ec, Nc * sizeof(float)));
-  const dim3 G((unsigned)std::min<unsigned long long>((N + 255) / 256, 8192ull)), B(256);
-  const dim3 Gc((unsigned)std::min<unsigned long long>((Nc + 255) / 256, 8192ull));
+// p = z + b p
+__global__ void __launch_bounds__(256) k_tg_xpay(float *__restrict__ p, const float *__restrict__ z, float b,
+                                                 unsigned long long n)
+{
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    p[i] = fmaf(b, p[i], z[i]);
+}
 
-  auto smooth = [&](int steps) {
+// the two grids, their work vectors and one cycle
+struct TwoGrid
+{
+  int d, L, nu1, nu2;
+  unsigned Lc;
+  unsigned long long N = 1, Nc = 1;
+  float w;
+  double coarse_rel;
+  Solver *coarse = nullptr;
+  hipStream_t s = nullptr;
+  float *Au = nullptr, *r = nullptr, *rc = nullptr, *ec = nullptr;
+  dim3 G, Gc, B{256};
+  int inner = 0;
+
+  TwoGrid(int L_, int d_, int nu1_, int nu2_, double omega, double coarse_rel_)
+      : d(d_), L(L_), nu1(nu1_), nu2(nu2_), coarse_rel(coarse_rel_)
+  {
+    CG_REQUIRE(d >= 1 && d <= 8, "the two-grid scheme is built for 1 <= d <= 8");
+    CG_REQUIRE(L >= 3 && (L & 1), "the two-grid scheme needs an odd number of points per axis, L = 2 Lc + 1 >= 3");
+    CG_REQUIRE(nu1 >= 0 && nu2 >= 0, "smoothing steps must not be negative");
+    Lc = (unsigned)(L - 1) / 2;
+    for (int k = 0; k < d; k++)
+    {
+      N *= (unsigned)L;
+      Nc *= Lc;
+    }
+    CG_REQUIRE(N < (1ull << 31), "grid must fit an int, as in the reference");
+    if (omega <= 0)
+      omega = 2.0 * d / (2.0 * d + 1.0); // the damping that smooths the upper half of the spectrum best
+    w = (float)(omega / (2.0 * d));
+    SolverDesc desc;
+    desc.d = d;
+    for (int k = 0; k < d; k++)
+      desc.extents[k] = Lc;
+    coarse = new Solver(desc);
+    s = coarse->stream();
+    CHECK(hipMalloc((void **)&Au, N * sizeof(float)));
+    CHECK(hipMalloc((void **)&r, N * sizeof(float)));
+    CHECK(hipMalloc((void **)&rc, Nc * sizeof(float)));
+    CHECK(hipMalloc((void **)&ec, Nc * sizeof(float)));
+    G = dim3((unsigned)std::min<unsigned long long>((N + 255) / 256, 8192ull));
+    Gc = dim3((unsigned)std::min<unsigned long long>((Nc + 255) / 256, 8192ull));
+  }
+  ~TwoGrid()
+  {
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(Au);
+    (void)hipFree(r);
+    (void)hipFree(rc);
+    (void)hipFree(ec);
+    delete coarse;
+  }
+  TwoGrid(const TwoGrid &) = delete;
+  TwoGrid &operator=(const TwoGrid &) = delete;
+
+  void smooth(float *u, const float *f, int steps)
+  {
     for (int k = 0; k < steps; k++)
     {
       laplace_apply(Au, u, d, (unsigned)L, 0, s);
       hipLaunchKernelGGL(k_tg_jacobi, G, B, 0, s, u, f, Au, w, N);
     }
-  };
-  auto residual_norm = [&]() -> double {
+  }
+  // r = f - A u
+  void residual(const float *u, const float *f)
+  {
     laplace_apply(Au, u, d, (unsigned)L, 0, s);
     hipLaunchKernelGGL(k_tg_residual, G, B, 0, s, r, f, Au, N);
     CHECK(hipGetLastError());
+  }
+  double residual_norm(const float *u, const float *f)
+  {
+    residual(u, f);
     return sqrt(dot_device(r, r, N, s));
-  };
+  }
+  // u <- TG(u) for the right-hand side f
+  void cycle(float *u, const float *f)
+  {
+    smooth(u, f, nu1);
+    residual(u, f);
+    hipLaunchKernelGGL(k_tg_restrict, Gc, B, 0, s, rc, r, d, (unsigned)L, Lc, Nc);
+    CHECK(hipMemsetAsync(ec, 0, Nc * sizeof(float), s));
+    coarse->begin(rc, ec, coarse_rel, 0);
+    coarse->run(100000, true);
+    inner += coarse->finish(nullptr, nullptr, 0);
+    hipLaunchKernelGGL(k_tg_prolong_add, G, B, 0, s, u, ec, d, (unsigned)L, Lc, N);
+    smooth(u, f, nu2);
+    CHECK(hipGetLastError());
+  }
+};
 
-  const double tol = rel * sqrt(dot_device(f, f, N, s));
-  int cycles = 0, inner = 0;
-  double res = residual_norm();
+} // namespace
+
+extern "C" int cg_two_grid_gpu(const float *f, float *u, int L, int d, int nu1, int nu2, double omega, int max_cycles,
+                               double rel, double coarse_rel, float *hist, int hist_len, int *coarse_iterations)
+{
+  CG_REQUIRE(max_cycles >= 0, "cycles must not be negative");
+  TwoGrid tg(L, d, nu1, nu2, omega, coarse_rel);
+  const double tol = rel * sqrt(dot_device(f, f, tg.N, tg.s));
+  int cycles = 0;
+  double res = tg.residual_norm(u, f);
   if (hist && hist_len > 0)
     hist[0] = (float)res;
   while (cycles < max_cycles && res > tol)
   {
-    smooth(nu1);
-    residual_norm(); // r = f - A u after pre-smoothing
-    hipLaunchKernelGGL(k_tg_restrict, Gc, B, 0, s, rc, r, d, (unsigned)L, Lc, Nc);
-    CHECK(hipMemsetAsync(ec, 0, Nc * sizeof(float), s));
-    coarse.begin(rc, ec, coarse_rel, 0);
-    coarse.run(100000, true);
-    inner += coarse.finish(nullptr, nullptr, 0);
-    hipLaunchKernelGGL(k_tg_prolong_add, G, B, 0, s, u, ec, d, (unsigned)L, Lc, N);
-    smooth(nu2);
-    res = residual_norm();
+    tg.cycle(u, f);
+    res = tg.residual_norm(u, f);
     cycles++;
     if (hist && cycles < hist_len)
       hist[cycles] = (float)res;
   }
+  CHECK(hipStreamSynchronize(tg.s));
+  if (coarse_iterations)
+    *coarse_iterations = tg.inner;
+  return cycles;
+}
+
+// CG preconditioned by one two-grid cycle from a zero guess, z = TG_f=r(0) (tasks.md:36).  With nu1 = nu2
+// and an accurate coarse solve the cycle is a symmetric positive definite operator; scalars on the host in
+// double, as in the mixed-precision driver.
+extern "C" int cg_two_grid_pcg_gpu(const float *f, float *u, int L, int d, int nu, double omega, int max_iters, double rel,
+                                   double coarse_rel, float *hist, int hist_len, int *coarse_iterations)
+{
+  CG_REQUIRE(max_iters >= 0, "iterations must not be negative");
+  TwoGrid tg(L, d, nu, nu, omega, coarse_rel);
+  const unsigned long long N = tg.N;
+  hipStream_t s = tg.s;
+  float *r, *z, *p, *q;
+  CHECK(hipMalloc((void **)&r, N * sizeof(float)));
+  CHECK(hipMalloc((void **)&z, N * sizeof(float)));
+  CHECK(hipMalloc((void **)&p, N * sizeof(float)));
+  CHECK(hipMalloc((void **)&q, N * sizeof(float)));
+  auto precondition = [&]() { // z = one cycle on A z = r from z = 0
+    CHECK(hipMemsetAsync(z, 0, N * sizeof(float), s));
+    tg.cycle(z, r);
+  };
+  const double tol = rel * sqrt(dot_device(f, f, N, s));
+  laplace_apply(q, u, d, (unsigned)L, 0, s);
+  hipLaunchKernelGGL(k_tg_residual, tg.G, tg.B, 0, s, r, f, q, N);
+  double res = sqrt(dot_device(r, r, N, s));
+  if (hist && hist_len > 0)
+    hist[0] = (float)res;
+  int it = 0;
+  if (res > tol && max_iters > 0)
+  {
+    precondition();
+    CHECK(hipMemcpyAsync(p, z, N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    double rz = dot_device(r, z, N, s);
+    while (it < max_iters)
+    {
+      it++;
+      laplace_apply(q, p, d, (unsigned)L, 0, s);
+      const double alpha = rz / dot_device(p, q, N, s);
+      hipLaunchKernelGGL(k_tg_update, tg.G, tg.B, 0, s, u, r, p, q, (float)alpha, N);
+      res = sqrt(dot_device(r, r, N, s));
+      if (hist && it < hist_len)
+        hist[it] = (float)res;
+      if (!(res > tol))
+        break;
+      precondition();
+      const double rz_new = dot_device(r, z, N, s);
+      hipLaunchKernelGGL(k_tg_xpay, tg.G, tg.B, 0, s, p, z, (float)(rz_new / rz), N);
+      rz = rz_new;
+    }
+  }
   CHECK(hipGetLastError());
   CHECK(hipStreamSynchronize(s));
-  CHECK(hipFree(Au));
   CHECK(hipFree(r));
-  CHECK(hipFree(rc));
-  CHECK(hipFree(ec));
+  CHECK(hipFree(z));
+  CHECK(hipFree(p));
+  CHECK(hipFree(q));
   if (coarse_iterations)
-    *coarse_iterations = inner;
-  return cycles;
+    *coarse_iterations = tg.inner;
+  return it;
 }

@@ -106,6 +106,12 @@ extern "C"
    * coarse_iterations (may be NULL) the CG iterations of all coarse solves.  Returns the cycles done. */
   int cg_two_grid_gpu(const float *f, float *u, int L, int d, int nu1, int nu2, double omega, int max_cycles,
                       double rel, double coarse_rel, float *hist, int hist_len, int *coarse_iterations);
+  /* CG preconditioned by one such cycle from a zero guess (nu steps before and after the coarse correction,
+   * tasks.md:36): u is the initial guess and the result, iterations until |f - A u| <= rel * |f| or
+   * max_iters.  hist: the residual norm before the first and after every iteration.  Returns the
+   * iterations done. */
+  int cg_two_grid_pcg_gpu(const float *f, float *u, int L, int d, int nu, double omega, int max_iters, double rel,
+                          double coarse_rel, float *hist, int hist_len, int *coarse_iterations);
 
   /* y = A u on device pointers, asynchronous on `stream` (a hipStream_t, may be NULL). */
   void cg_laplace_device(float *ddf, const float *u, int d, int L, int index_mode, void *stream);

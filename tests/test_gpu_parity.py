@@ -818,3 +818,22 @@ def test_two_grid_transfer_operators(lib, Lc, d):
         cycles, hist, inner = lib.two_grid_gpu(f.data_ptr(), u.data_ptr(), L, d, nu1=0, nu2=0, max_cycles=1, rel=0.0, coarse_rel=1e-7)
         assert rel_l2(u.cpu().numpy(), pe) <= 1e-4
         assert hist[1] <= 1e-3 * hist[0]
+
+
+@pytest.mark.parametrize("L,d", [(63, 2), (31, 3), (127, 2)])
+def test_cg_preconditioned_by_a_two_grid_cycle(lib, oracle, L, d):
+    """One symmetric two-grid cycle (2+2 Jacobi steps) as M^-1: preconditioned CG needs fewer iterations
+    than stand-alone cycles and far fewer than plain CG, and ends at the same solution."""
+    N = L ** d
+    rng = np.random.default_rng(3 * L + d)
+    xt = rng.random(N).astype(np.float32)
+    f = oracle.laplace_f32(xt, d, L)
+    fd = dev(f)
+    u = torch.zeros(N, dtype=torch.float32, device="cuda")
+    its, hist, inner = lib.two_grid_pcg_gpu(fd.data_ptr(), u.data_ptr(), L, d, max_iters=30, rel=1e-5)
+    cycles, _, _ = lib.two_grid_gpu(fd.data_ptr(), torch.zeros_like(u).data_ptr(), L, d, max_cycles=30, rel=1e-5)
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    _, cg_iters, _ = lib.conjugate_gradient_gpu_ex(fd.data_ptr(), x.data_ptr(), L, d, maxit=5000, rel=1e-5, lagged=0)
+    assert 1 <= its <= cycles < cg_iters, (its, cycles, cg_iters)
+    assert hist[its] <= 1e-5 * np.linalg.norm(f) * 1.01
+    assert np.all(np.abs(u.cpu().numpy() - xt) < 1e-3)   # the reference's recover-x bar (tests.cu:14-41)
