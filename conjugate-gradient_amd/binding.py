@@ -17,7 +17,7 @@ EXPORTS = [
     "time_cpu_laplace", "add_jl", "laplace_gpu_jl",
     # part 2: additions
     "cg_allocate_field", "cg_free_field", "conjugate_gradient_gpu_ex", "preconditioned_cg_gpu",
-    "cg_eigen_extremes_gpu", "cg_two_grid_gpu", "cg_two_grid_pcg_gpu",
+    "cg_eigen_extremes_gpu", "cg_two_grid_gpu", "cg_two_grid_pcg_gpu", "cg_multigrid_gpu",
     "cg_laplace_device", "cg_fill_uniform", "cg_u01_host", "cg_strong_scaling_events", "cg_laplace_time_events",
     "cg_solver_buffer_len", "cg_solver_ghost_offset", "cg_solver_plane", "cg_solver_create",
     "cg_solver_destroy", "cg_solver_engine", "cg_solver_blocks", "cg_solver_kernel_name", "cg_solver_begin", "cg_solver_iterate",
@@ -92,6 +92,9 @@ class Library:
         c.cg_two_grid_gpu.restype = i32
         c.cg_two_grid_pcg_gpu.argtypes = [vp, vp, i32, i32, i32, C.c_double, i32, C.c_double, C.c_double, vp, i32, vp]
         c.cg_two_grid_pcg_gpu.restype = i32
+        c.cg_multigrid_gpu.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_double, i32, C.c_double, C.c_double, vp, i32,
+                                       vp, vp]
+        c.cg_multigrid_gpu.restype = i32
         c.cg_laplace_device.argtypes = [fp, fp, i32, i32, i32, vp]
         c.cg_laplace_device.restype = None
         c.cg_fill_uniform.argtypes = [fp, C.c_ulonglong, u32]
@@ -229,6 +232,14 @@ class Library:
         cycles = self.c.cg_two_grid_gpu(_ptr(f), _ptr(u), L, d, nu1, nu2, omega, max_cycles, rel, coarse_rel,
                                         C.cast(hist, C.c_void_p), max_cycles + 1, C.byref(inner))
         return cycles, list(hist)[:cycles + 1], inner.value
+
+    def multigrid_gpu(self, f, u, L, d, levels=0, nu1=2, nu2=2, omega=0.0, max_cycles=50, rel=1e-6, coarse_rel=1e-4):
+        """V-cycles.  Returns (cycles, [residual norms], levels in use, CG iterations on the coarsest grid)."""
+        hist = (C.c_float * (max_cycles + 1))()
+        used, inner = C.c_int(0), C.c_int(0)
+        cycles = self.c.cg_multigrid_gpu(_ptr(f), _ptr(u), L, d, levels, nu1, nu2, omega, max_cycles, rel, coarse_rel,
+                                         C.cast(hist, C.c_void_p), max_cycles + 1, C.byref(used), C.byref(inner))
+        return cycles, list(hist)[:cycles + 1], used.value, inner.value
 
     def two_grid_pcg_gpu(self, f, u, L, d, nu=2, omega=0.0, max_iters=50, rel=1e-6, coarse_rel=1e-4):
         """CG preconditioned by one two-grid cycle.  Returns (iterations, [residual norms], coarse CG iterations)."""

@@ -176,13 +176,16 @@ struct TwoGrid
   unsigned long long N = 1, Nc = 1;
   float w;
   double coarse_rel;
-  Solver *coarse = nullptr;
+  Solver *coarse = nullptr;  // the coarse-grid solver of the last level ...
+  TwoGrid *child = nullptr;  // ... or the same scheme on the coarse grid (a V-cycle over several levels)
   hipStream_t s = nullptr;
   float *Au = nullptr, *r = nullptr, *rc = nullptr, *ec = nullptr;
   dim3 G, Gc, B{256};
   int inner = 0;
 
-  TwoGrid(int L_, int d_, int nu1_, int nu2_, double omega, double coarse_rel_)
+  // levels: grids in the hierarchy, this one included (2: the two-grid scheme); coarsening stops early
+  // at a grid whose coarse grid would have an even number of points per axis or fewer than 3
+  TwoGrid(int L_, int d_, int nu1_, int nu2_, double omega, double coarse_rel_, int levels = 2)
       : d(d_), L(L_), nu1(nu1_), nu2(nu2_), coarse_rel(coarse_rel_)
   {
     CG_REQUIRE(d >= 1 && d <= 8, "the two-grid scheme is built for 1 <= d <= 8");
@@ -198,12 +201,20 @@ struct TwoGrid
     if (omega <= 0)
       omega = 2.0 * d / (2.0 * d + 1.0); // the damping that smooths the upper half of the spectrum best
     w = (float)(omega / (2.0 * d));
-    SolverDesc desc;
-    desc.d = d;
-    for (int k = 0; k < d; k++)
-      desc.extents[k] = Lc;
-    coarse = new Solver(desc);
-    s = coarse->stream();
+    if (levels > 2 && (Lc & 1u) && Lc >= 7)
+    {
+      child = new TwoGrid((int)Lc, d, nu1, nu2, omega, coarse_rel, levels - 1);
+      s = child->s;
+    }
+    else
+    {
+      SolverDesc desc;
+      desc.d = d;
+      for (int k = 0; k < d; k++)
+        desc.extents[k] = Lc;
+      coarse = new Solver(desc);
+      s = coarse->stream();
+    }
     CHECK(hipMalloc((void **)&Au, N * sizeof(float)));
     CHECK(hipMalloc((void **)&r, N * sizeof(float)));
     CHECK(hipMalloc((void **)&rc, Nc * sizeof(float)));
@@ -218,8 +229,11 @@ struct TwoGrid
     (void)hipFree(r);
     (void)hipFree(rc);
     (void)hipFree(ec);
+    delete child;
     delete coarse;
   }
+  int levels() const { return child ? 1 + child->levels() : 2; }
+  int coarse_iterations() const { return child ? child->coarse_iterations() : inner; }
   TwoGrid(const TwoGrid &) = delete;
   TwoGrid &operator=(const TwoGrid &) = delete;
 
@@ -250,9 +264,14 @@ struct TwoGrid
     residual(u, f);
     hipLaunchKernelGGL(k_tg_restrict, Gc, B, 0, s, rc, r, d, (unsigned)L, Lc, Nc);
     CHECK(hipMemsetAsync(ec, 0, Nc * sizeof(float), s));
-    coarse->begin(rc, ec, coarse_rel, 0);
-    coarse->run(100000, true);
-    inner += coarse->finish(nullptr, nullptr, 0);
+    if (child)
+      child->cycle(ec, rc);
+    else
+    {
+      coarse->begin(rc, ec, coarse_rel, 0);
+      coarse->run(100000, true);
+      inner += coarse->finish(nullptr, nullptr, 0);
+    }
     hipLaunchKernelGGL(k_tg_prolong_add, G, B, 0, s, u, ec, d, (unsigned)L, Lc, N);
     smooth(u, f, nu2);
     CHECK(hipGetLastError());
@@ -282,6 +301,35 @@ extern "C" int cg_two_grid_gpu(const float *f, float *u, int L, int d, int nu1, 
   CHECK(hipStreamSynchronize(tg.s));
   if (coarse_iterations)
     *coarse_iterations = tg.inner;
+  return cycles;
+}
+
+// The same with the coarse problem handed to the scheme itself: V-cycles over `levels` grids (0: as many
+// as the grid allows), CG only on the coarsest.
+extern "C" int cg_multigrid_gpu(const float *f, float *u, int L, int d, int levels, int nu1, int nu2, double omega,
+                                int max_cycles, double rel, double coarse_rel, float *hist, int hist_len, int *levels_used,
+                                int *coarse_iterations)
+{
+  CG_REQUIRE(max_cycles >= 0 && levels >= 0 && levels != 1, "cycles must not be negative; levels is 0 or at least 2");
+  TwoGrid mg(L, d, nu1, nu2, omega, coarse_rel, levels == 0 ? 64 : levels);
+  const double tol = rel * sqrt(dot_device(f, f, mg.N, mg.s));
+  int cycles = 0;
+  double res = mg.residual_norm(u, f);
+  if (hist && hist_len > 0)
+    hist[0] = (float)res;
+  while (cycles < max_cycles && res > tol)
+  {
+    mg.cycle(u, f);
+    res = mg.residual_norm(u, f);
+    cycles++;
+    if (hist && cycles < hist_len)
+      hist[cycles] = (float)res;
+  }
+  CHECK(hipStreamSynchronize(mg.s));
+  if (levels_used)
+    *levels_used = mg.levels();
+  if (coarse_iterations)
+    *coarse_iterations = mg.coarse_iterations();
   return cycles;
 }
 

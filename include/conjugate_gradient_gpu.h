@@ -106,6 +106,12 @@ extern "C"
    * coarse_iterations (may be NULL) the CG iterations of all coarse solves.  Returns the cycles done. */
   int cg_two_grid_gpu(const float *f, float *u, int L, int d, int nu1, int nu2, double omega, int max_cycles,
                       double rel, double coarse_rel, float *hist, int hist_len, int *coarse_iterations);
+  /* The same scheme with the coarse problem handed to the scheme itself: V-cycles over `levels` grids
+   * (0: as many as the grid allows; coarsening needs an odd number of points per axis on every level but
+   * the last, e.g. L = 2^k - 1), CG only on the coarsest.  levels_used (may be NULL): the grids in use. */
+  int cg_multigrid_gpu(const float *f, float *u, int L, int d, int levels, int nu1, int nu2, double omega,
+                       int max_cycles, double rel, double coarse_rel, float *hist, int hist_len, int *levels_used,
+                       int *coarse_iterations);
   /* CG preconditioned by one such cycle from a zero guess (nu steps before and after the coarse correction,
    * tasks.md:36): u is the initial guess and the result, iterations until |f - A u| <= rel * |f| or
    * max_iters.  hist: the residual norm before the first and after every iteration.  Returns the

@@ -837,3 +837,27 @@ def test_cg_preconditioned_by_a_two_grid_cycle(lib, oracle, L, d):
     assert 1 <= its <= cycles < cg_iters, (its, cycles, cg_iters)
     assert hist[its] <= 1e-5 * np.linalg.norm(f) * 1.01
     assert np.all(np.abs(u.cpu().numpy() - xt) < 1e-3)   # the reference's recover-x bar (tests.cu:14-41)
+
+
+@pytest.mark.parametrize("L,d,levels", [(127, 2, 0), (63, 3, 0), (1023, 1, 0), (255, 2, 3), (45, 2, 0)])
+def test_multigrid_v_cycles(lib, oracle, L, d, levels):
+    """V-cycles over all the levels the grid allows (L = 2^k - 1 coarsens down to 3 points per axis; 45 ->
+    22 stops after one coarsening) contract the residual at a rate independent of the size, and with two
+    levels the scheme is the two-grid scheme bit for bit."""
+    N = L ** d
+    rng = np.random.default_rng(L + 7 * d)
+    xt = rng.random(N).astype(np.float32)
+    f = oracle.laplace_f32(xt, d, L)
+    fd = dev(f)
+    u = torch.zeros(N, dtype=torch.float32, device="cuda")
+    cycles, hist, used, inner = lib.multigrid_gpu(fd.data_ptr(), u.data_ptr(), L, d, levels=levels, max_cycles=30, rel=1e-5)
+    want = {(127, 2, 0): 6, (63, 3, 0): 5, (1023, 1, 0): 9, (255, 2, 3): 3, (45, 2, 0): 2}[(L, d, levels)]
+    assert used == want, used
+    assert 2 <= cycles < 30
+    assert max(hist[k + 1] / hist[k] for k in range(min(cycles, 5))) < 0.4
+    assert hist[cycles] <= 1e-5 * np.linalg.norm(f) * 1.01
+    assert np.all(np.abs(u.cpu().numpy() - xt) < 1e-3)
+    if L == 45:
+        v = torch.zeros(N, dtype=torch.float32, device="cuda")
+        c2, h2, _ = lib.two_grid_gpu(fd.data_ptr(), v.data_ptr(), L, d, max_cycles=30, rel=1e-5)
+        assert c2 == cycles and h2 == hist and torch.equal(u, v)

@@ -17,7 +17,7 @@ lib = load_package().load_library()
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 Ls = [int(v) for v in sys.argv[2:]] or [63, 127, 255, 511, 1023, 2047]
 rel = 1e-5
-print("d,L,N,tg_cycles,tg_coarse_cg_iterations,tg_ms,tg_factor_first_cycles,tgpcg_iterations,tgpcg_ms,cg_iterations,cg_ms")
+print("d,L,N,tg_cycles,tg_coarse_cg_iterations,tg_ms,tg_factor_first_cycles,tgpcg_iterations,tgpcg_ms,mg_levels,mg_cycles,mg_ms,cg_iterations,cg_ms")
 for L in Ls:
     N = L ** d
     xt = torch.empty(N, dtype=torch.float32, device="cuda")
@@ -36,10 +36,15 @@ for L in Ls:
         t0 = time.perf_counter()
         pits, _, _ = lib.two_grid_pcg_gpu(f.data_ptr(), v.data_ptr(), L, d, max_iters=60, rel=rel)
         t_pcg = time.perf_counter() - t0
+        m = torch.zeros(N, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mcyc, _, mlev, _ = lib.multigrid_gpu(f.data_ptr(), m.data_ptr(), L, d, max_cycles=60, rel=rel)
+        t_mg = time.perf_counter() - t0
         x = torch.zeros(N, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         _, iters, _ = lib.conjugate_gradient_gpu_ex(f.data_ptr(), x.data_ptr(), L, d, maxit=200000, rel=rel, lagged=0)
         t_cg = time.perf_counter() - t0
     fac = (hist[min(cycles, 3)] / hist[0]) ** (1.0 / min(cycles, 3)) if cycles else 0.0
-    print(f"{d},{L},{N},{cycles},{inner},{t_tg * 1e3:.2f},{fac:.3f},{pits},{t_pcg * 1e3:.2f},{iters},{t_cg * 1e3:.2f}", flush=True)
+    print(f"{d},{L},{N},{cycles},{inner},{t_tg * 1e3:.2f},{fac:.3f},{pits},{t_pcg * 1e3:.2f},{mlev},{mcyc},{t_mg * 1e3:.2f},{iters},{t_cg * 1e3:.2f}", flush=True)
