@@ -34,6 +34,9 @@ namespace cgamd
 // Measured, kernels A / B in us without -> with: 128^4 780 / 946 -> 725 / 895, 64x64x64x512 388 / 578 ->
 // 360 / 463, 64^4 x 16 1271 / 1300 -> 1384 / 1156, 96^4 406 / 452 -> 500 / 449, 48^5 1229 / 1125 -> 1383 /
 // 1081: kernel B always gains, kernel A only in 4-D with rows that fill their lanes (the host chooses).
+// Exact rows (g.xl, both kernels through LDS): a row whose n0/4 lanes are not a power of two would idle up
+// to half of its slot; instead it takes exactly n0/4 lanes, rows cross wave boundaries, and the x
+// neighbours of a lane come from LDS as well instead of from lane shifts.
 template <int MODE, bool GHOST, int D, int R, bool STREAM, bool LDS>
 __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
 {
@@ -87,8 +90,11 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
     const unsigned x0 = ((unsigned)tid % g.sub) * 4u;
     // a row holds n0/4 lanes rounded up to a power of two; idle lanes (past the end of the row, past
     // the last column) shadow a valid quad and store nothing
-    const bool act = c < g.ncols && x0 < g.n0;
-    unsigned hi = c < g.ncols ? c : g.ncols - 1u;
+    // (exact rows, g.xl: a row takes exactly n0/4 lanes and the lanes left over at the end of the
+    // workgroup form no slot)
+    const bool slot = cs < g.cpg;
+    const bool act = slot && c < g.ncols && x0 < g.n0;
+    unsigned hi = (slot && c < g.ncols) ? c : g.ncols - 1u;
     long long base = x0 < g.n0 ? x0 : ((g.n0 + 3u) & ~3u) - 4u;
     unsigned okm = 0, okp = 0;
 #pragma unroll
@@ -256,12 +262,23 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
       {
         const long long ij = idx + j * sb;
         const float4 q = pc[j];
-        float lft = __shfl_up(q.w, 1);
-        float rgt = __shfl_down(q.x, 1);
-        if (first) // the grid face, not the previous lane's row
-          lft = 0.0f;
-        if (rightmost)
-          rgt = 0.0f;
+        float lft, rgt;
+        if (LDS && g.xl)
+        {
+          // exact rows cross wave boundaries: the x neighbours come from the rows just handed to LDS
+          const float4 *mine = hand + (size_t)(y & 1) * R * 512 + tid + j * 512;
+          lft = (first || !slot) ? 0.0f : mine[-1].w;
+          rgt = (rightmost || !slot) ? 0.0f : mine[1].x;
+        }
+        else
+        {
+          lft = __shfl_up(q.w, 1);
+          rgt = __shfl_down(q.x, 1);
+          if (first) // the grid face, not the previous lane's row
+            lft = 0.0f;
+          if (rightmost)
+            rgt = 0.0f;
+        }
         float4 lv;
         lv.x = 0.0f + axis_term(q.y, q.x, lft);
         lv.y = 0.0f + axis_term(q.z, q.y, q.x);

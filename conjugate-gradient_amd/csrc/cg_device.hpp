@@ -112,6 +112,7 @@ struct RowsGeom
   unsigned nb;           // extent of axis d-2
   unsigned long long sb; // its stride
   int stream;            // k_cols: single-use traffic carries the streaming hint
+  int xl;                // k_cols: a row takes exactly n0/4 lanes (x neighbours through LDS too)
   int lds_a, lds_b;      // k_cols, kernels A (and the plain stencil) / B: axis-1 neighbours inside a workgroup travel through LDS
 };
 

@@ -273,6 +273,16 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
         // neighbours along axis 1 through LDS (see k_cols): kernel B always, kernel A where it measured faster
         g.lds_b = env_int("CG_COLS_LDS_B", 1);
         g.lds_a = env_int("CG_COLS_LDS_A", (d == 4 && sub == lanes) ? 1 : 0);
+        // rows that leave more than a tenth of their power-of-two slot idle take exactly n0/4 lanes, on large
+        // grids in d <= 4 (kernels A / B: 100^4 387 / 390 -> 345 / 358 us, 80^4 153 / 175 -> 144 / 148, 96^4
+        // 313 / 340 -> 317 / 302; 48^5 loses 8 %, grids of a few million points up to 20 % in kernel A)
+        if (n[0] % 4 == 0 && lanes * 10 < sub * 9 && env_int("CG_COLS_EXACT", (d <= 4 && big) ? 1 : 0))
+        {
+          g.xl = 1;
+          g.lds_a = g.lds_b = 1;
+          g.sub = lanes;
+          g.cpg = (unsigned)block / lanes;
+        }
       }
       ncols = (nc + g.cpg - 1) / g.cpg; // column groups
     }

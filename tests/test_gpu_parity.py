@@ -411,6 +411,7 @@ def test_morton_tiled_engine_equals_lexicographic_large(lib, oracle, monkeypatch
     tiles: stencil bit-exact, 30 CG iterations to rounding.  The solve runs either on the LDS-tiled
     Z-curve kernels (relayout 0) or, the default, in lexicographic order inside the solver with b and
     x permuted on the way in and out."""
+    monkeypatch.delenv("CG_ENGINE", raising=False)   # a forced engine keeps the Z-curve kernels
     monkeypatch.setenv("CG_MORTON_RELAYOUT", relayout)
     N = L ** d
     perm = morton_perm(L, d)
@@ -546,11 +547,13 @@ def test_engines_agree_on_non_cubic_grids(lib, ext):
         assert rel_l2(xe, ref_x) <= 1e-5, engine
 
 
+@pytest.mark.parametrize("exact", ["0", "1"])
 @pytest.mark.parametrize("R,stream", [(2, 0), (2, 1), (1, 1), (0, 0)])
 @pytest.mark.parametrize("ext", [[64, 6, 4, 5], [32, 3, 6, 7], [16, 5, 3, 4], [128, 9, 2, 3], [32, 4, 3, 2, 6], [16, 3, 2, 4, 5],
-                                 [16, 2, 2, 2, 2], [64, 40, 34, 9], [64, 90, 7], [128, 33, 5], [48, 200, 30], [200, 70, 3]],
+                                 [16, 2, 2, 2, 2], [64, 40, 34, 9], [64, 90, 7], [128, 33, 5], [48, 200, 30], [200, 70, 3],
+                                 [96, 10, 6, 5], [20, 9, 8, 7], [80, 12, 6], [24, 6, 4, 4, 3], [100, 7, 6, 5]],
                          ids=lambda e: "x".join(map(str, e)))
-def test_blocked_columns_match_the_scalar_engine(lib, monkeypatch, ext, R, stream):
+def test_blocked_columns_match_the_scalar_engine(lib, monkeypatch, ext, R, stream, exact):
     """3-D to 5-D grids with short rows: R columns per lane along axis d-2, neighbours fetched two
     steps ahead, with and without the streaming hint (the automatic choice depends on the grid's
     size), and the fall-back to one column per lane when axis d-2 has an odd extent.  The stencil must
@@ -558,6 +561,7 @@ def test_blocked_columns_match_the_scalar_engine(lib, monkeypatch, ext, R, strea
     monkeypatch.delenv("CG_ENGINE", raising=False)
     monkeypatch.setenv("CG_COLS_R", str(R))
     monkeypatch.setenv("CG_COLS_STREAM", str(stream))
+    monkeypatch.setenv("CG_COLS_EXACT", exact)   # rows of exactly n0/4 lanes (x neighbours through LDS)
     N = int(np.prod(ext))
     b = torch.empty(N, dtype=torch.float32, device="cuda")
     lib.c.cg_fill_uniform(b.data_ptr(), N, 33)

@@ -93,13 +93,15 @@ def test_virtual_ranks_match_single_gpu_and_oracle(pkg, lib, oracle, engine_env,
 
 
 @pytest.mark.parametrize("L,d,nranks,R,stream", [(16, 4, 2, 2, 1), (16, 4, 4, 1, 0), (16, 5, 2, 2, 1), (16, 5, 2, 2, 0),
-                                                  (32, 3, 2, 2, 1), (64, 3, 4, 1, 0)])
+                                                  (32, 3, 2, 2, 1), (64, 3, 4, 1, 0), (24, 4, 2, 2, 1), (48, 3, 2, 2, 0),
+                                                  (20, 4, 2, 1, 0)])
 def test_blocked_columns_on_slabs(pkg, lib, monkeypatch, L, d, nranks, R, stream):
     """Slabs of 4-D and 5-D grids with short rows run the columns-in-blocks kernels with ghost planes
     on the marching axis: same solution as one solver on the whole grid."""
     monkeypatch.setenv("CG_ENGINE", "1")
     monkeypatch.setenv("CG_COLS_R", str(R))
     monkeypatch.setenv("CG_COLS_STREAM", str(stream))
+    monkeypatch.setenv("CG_COLS_EXACT", "1")   # rows of 24, 48, 20 points: exactly n0/4 lanes each
     N = L ** d
     bd = torch.empty(N, dtype=torch.float32, device="cuda")
     lib.c.cg_fill_uniform(bd.data_ptr(), N, 5)
