@@ -157,7 +157,7 @@ extern "C" unsigned int neighbour_index_gpu(unsigned int ind, int direction, int
     if (amount == 0)
       return ind;
     const unsigned int m = morton_mask((int)d, direction);
-    const unsigned int nb = amount > 0 ? morton_inc(ind, m) : morton_dec(ind, m);
+    const unsigned int nb = amount > 0 ? morton_up(ind, m, N) : morton_dn(ind, m, N);
     return nb < N ? nb : N;
   }
   return lex_neighbour(ind, direction, amount, L, N);

@@ -724,8 +724,8 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
       for (int k = 0; k < g.d; k++)
       {
         const unsigned m = g.mmask[k];
-        const unsigned ip = morton_inc(ii, m);
-        const unsigned im = morton_dec(ii, m);
+        const unsigned ip = morton_up(ii, m, g.N);
+        const unsigned im = morton_dn(ii, m, g.N);
         const float up = ip < g.N ? src.ld1((long long)ip) : 0.0f;
         const float um = im < g.N ? src.ld1((long long)im) : 0.0f;
         lv = lv + axis_term(up, c, um);

@@ -81,11 +81,11 @@ __global__ void __launch_bounds__(256) k_morton4(const MortonGeom g, const VecAr
       rv = load4<false>(a.r + i);
     }
     // axis 0: elements 0,2 have bit 0 clear, elements 1,3 have it set
-    const float4 xp = quad(morton_inc(i + 1u, m0)); // +1 of elements 1 and 3: its elements 0 and 2
-    const float4 xm = quad(morton_dec(i, m0));      // -1 of elements 0 and 2: its elements 1 and 3
+    const float4 xp = quad(morton_up(i + 1u, m0, N)); // +1 of elements 1 and 3: its elements 0 and 2
+    const float4 xm = quad(morton_dn(i, m0, N));      // -1 of elements 0 and 2: its elements 1 and 3
     // axis 1: elements 0,1 have bit 1 clear, elements 2,3 have it set
-    const float4 yp = quad(morton_inc(i + 2u, m1)); // +1 of elements 2 and 3: its elements 0 and 1
-    const float4 ym = quad(morton_dec(i, m1));      // -1 of elements 0 and 1: its elements 2 and 3
+    const float4 yp = quad(morton_up(i + 2u, m1, N)); // +1 of elements 2 and 3: its elements 0 and 1
+    const float4 ym = quad(morton_dn(i, m1, N));      // -1 of elements 0 and 1: its elements 2 and 3
     float4 lv;
     lv.x = 0.0f + axis_term(c.y, c.x, xm.y);
     lv.y = 0.0f + axis_term(xp.x, c.y, c.x);
@@ -98,8 +98,8 @@ __global__ void __launch_bounds__(256) k_morton4(const MortonGeom g, const VecAr
     for (int k = 2; k < g.d; k++)
     {
       const unsigned m = g.mmask[k];
-      const float4 up = quad(morton_inc(i, m));
-      const float4 um = quad(morton_dec(i, m));
+      const float4 up = quad(morton_up(i, m, N));
+      const float4 um = quad(morton_dn(i, m, N));
       lv.x += axis_term(up.x, c.x, um.x);
       lv.y += axis_term(up.y, c.y, um.y);
       lv.z += axis_term(up.z, c.z, um.z);
@@ -252,10 +252,10 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
       const unsigned ql = threadIdx.x + (unsigned)CG_MORTON_BT * s;
       const unsigned i = base + (ql << 2);
       const float4 cc = c[s];
-      const float4 xp = quad(morton_inc(i + 1u, m0));
-      const float4 xm = quad(morton_dec(i, m0));
-      const float4 yp = quad(morton_inc(i + 2u, m1));
-      const float4 ym = quad(morton_dec(i, m1));
+      const float4 xp = quad(morton_up(i + 1u, m0, N));
+      const float4 xm = quad(morton_dn(i, m0, N));
+      const float4 yp = quad(morton_up(i + 2u, m1, N));
+      const float4 ym = quad(morton_dn(i, m1, N));
       float4 lv;
       lv.x = 0.0f + axis_term(cc.y, cc.x, xm.y);
       lv.y = 0.0f + axis_term(xp.x, cc.y, cc.x);
@@ -268,8 +268,8 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
       for (int k = 2; k < g.d; k++)
       {
         const unsigned m = g.mmask[k];
-        const float4 up = quad(morton_inc(i, m));
-        const float4 um = quad(morton_dec(i, m));
+        const float4 up = quad(morton_up(i, m, N));
+        const float4 um = quad(morton_dn(i, m, N));
         lv.x += axis_term(up.x, cc.x, um.x);
         lv.y += axis_term(up.y, cc.y, um.y);
         lv.z += axis_term(up.z, cc.z, um.z);

@@ -101,9 +101,9 @@ __global__ void __launch_bounds__(CG_SMALL_THREADS) k_small(const SmallGeom g, c
       {
         for (int ax = 0; ax < d; ax++)
         {
-          if (morton_inc(i, g.mmask[ax]) < g.N)
+          if (morton_up(i, g.mmask[ax], g.N) < g.N)
             bits |= 1u << (2 * ax);
-          if (morton_dec(i, g.mmask[ax]) < g.N)
+          if (morton_dn(i, g.mmask[ax], g.N) < g.N)
             bits |= 2u << (2 * ax);
         }
       }

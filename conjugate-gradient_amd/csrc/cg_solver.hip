@@ -395,6 +395,17 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   CG_REQUIRE(N_ < (1ull << 32), "grid must have fewer than 2^32 points");
   layout_ = desc.index_mode == 2 ? LAYOUT_MORTON : LAYOUT_LEX;
   CG_REQUIRE(desc.index_mode >= 0 && desc.index_mode <= 2, "index_mode must be 0, 1 (lexicographic) or 2 (Morton)");
+  // A hypercube of two points per axis has the same index in both layouts (bit k = coordinate k): the
+  // quad-per-lane Morton kernels serve it (2^24: kernels A / B 485 / 404 -> 205 / 154 us)
+  if (layout_ == LAYOUT_LEX && desc.d >= 2 && !desc.has_lo && !desc.has_hi && desc.engine == ENGINE_AUTO &&
+      env_int("CG_ENGINE", 0) == 0)
+  {
+    bool twos = true;
+    for (int k = 0; k < desc.d; k++)
+      twos = twos && desc.extents[k] == 2;
+    if (twos)
+      layout_ = LAYOUT_MORTON;
+  }
   CG_REQUIRE(!(desc.has_lo || desc.has_hi) || (layout_ == LAYOUT_LEX && desc.d >= 2),
              "slab neighbours need the lexicographic layout and d >= 2");
   // padded rows (see cg_solver.hpp): only for stand-alone grids with the automatic engine choice,
@@ -1300,7 +1311,9 @@ void Solver::time_kernels(int n, float *ms_A, float *ms_B)
 void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode, hipStream_t stream)
 {
   CG_REQUIRE(d >= 1 && d <= CG_MAXD, "dimension must be in [1,32]");
-  const int layout = index_mode == 2 ? LAYOUT_MORTON : LAYOUT_LEX;
+  // two points per axis: bit k of the lexicographic index is coordinate k, which is the Z-curve index too,
+  // so such a hypercube runs on the quad-per-lane Morton kernels (d = 24: 412 -> 129 us)
+  const int layout = (index_mode == 2 || (L == 2 && d >= 2)) ? LAYOUT_MORTON : LAYOUT_LEX;
   ScalarGeom sg{};
   sg.d = d;
   unsigned long long s = 1;

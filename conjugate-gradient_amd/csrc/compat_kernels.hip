@@ -35,7 +35,7 @@ __global__ void laplace_gpu(float *ddf, float *u, unsigned int d, unsigned int L
     for (unsigned int k = 0; k < d; k++)
     {
       const unsigned int m = base << k;
-      const unsigned int ip = morton_inc(ind, m), im = morton_dec(ind, m);
+      const unsigned int ip = morton_up(ind, m, N), im = morton_dn(ind, m, N);
       const float up = ip < N ? u[ip] : 0.0f;
       const float um = im < N ? u[im] : 0.0f;
       laplace_value = laplace_value + ((-up + 2.0f * c) - um);

@@ -69,6 +69,22 @@ CG_HD unsigned int morton_inc(unsigned int idx, unsigned int mask)
   return (idx & ~mask) | ((((idx & mask) | ~mask) + 1u) & mask);
 }
 
+// The same two steps for a grid of N = 2^(m d) points, with 0xffffffff for a step that leaves it.  The
+// reference detects that by "index >= N" (interleave.cuh:99), which needs a spare mask bit above the m
+// coordinate bits for the carry or borrow to land in; for d (m + 1) > 32 some masks have none and the step
+// wraps around to a valid-looking index (L = 2, d >= 17).  Looking at the coordinate's own bits is
+// equivalent wherever the reference's test works, and right everywhere.
+CG_HD unsigned int morton_up(unsigned int idx, unsigned int mask, unsigned long long N)
+{
+  const unsigned int cm = mask & (unsigned int)(N - 1ull);
+  return (idx & cm) == cm ? 0xffffffffu : morton_inc(idx, mask);
+}
+CG_HD unsigned int morton_dn(unsigned int idx, unsigned int mask, unsigned long long N)
+{
+  const unsigned int cm = mask & (unsigned int)(N - 1ull);
+  return (idx & cm) == 0u ? 0xffffffffu : morton_dec(idx, mask);
+}
+
 // _pdep_u32 without BMI2 (custom_pdep.cpp:4-8)
 CG_HD unsigned int pdep32(unsigned int x, unsigned int mask)
 {

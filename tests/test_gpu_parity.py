@@ -74,7 +74,7 @@ def test_inner_product_host_pointer(lib):
 
 # ---- stencil ---------------------------------------------------------------------------
 
-STENCIL_CASES = [(1000, 1), (1024, 1), (4, 1), (1000 * 1100, 1), (312 * 4000, 1), (10, 2), (5, 3), (64, 2), (256, 2), (12, 3), (16, 3), (32, 3),
+STENCIL_CASES = [(1000, 1), (1024, 1), (4, 1), (1000 * 1100, 1), (312 * 4000, 1), (2, 20), (2, 13), (2, 2), (10, 2), (5, 3), (64, 2), (256, 2), (12, 3), (16, 3), (32, 3),
                  (8, 4), (6, 4), (4, 5), (2, 10), (260, 2), (100, 3), (16, 4), (64, 3), (128, 3), (16, 5),
                  (1 << 20, 1), (3 << 20, 1)]
 
@@ -865,3 +865,28 @@ def test_multigrid_v_cycles(lib, oracle, L, d, levels):
         v = torch.zeros(N, dtype=torch.float32, device="cuda")
         c2, h2, _ = lib.two_grid_gpu(fd.data_ptr(), v.data_ptr(), L, d, max_cycles=30, rel=1e-5)
         assert c2 == cycles and h2 == hist and torch.equal(u, v)
+
+
+
+def test_hypercube_of_two_points_per_axis_runs_on_the_quad_kernels(lib, monkeypatch):
+    """L = 2: bit k of the lexicographic index is coordinate k, i.e. the index is its own Z-curve index, and
+    the solver hands such grids to the quad-per-lane Morton kernels.  Same CG as the one-point-per-lane
+    engine (the end point of the reference's dimension sweep, main.jl:85-116, is 2^24)."""
+    monkeypatch.delenv("CG_ENGINE", raising=False)
+    d = 20
+    N = 2 ** d
+    b = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(b.data_ptr(), N, 9)
+    outs = []
+    for engine in (0, 2):
+        s = lib.make_solver([2] * d, engine=engine)
+        assert s.kernel_name.startswith("k_morton") == (engine == 0), s.kernel_name
+        x = torch.zeros(N, dtype=torch.float32, device="cuda")
+        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.iterate(12, use_graph=True)
+        iters, res, hist = s.finish(hist_len=12)
+        assert iters == 12
+        outs.append((x.cpu().numpy(), np.array(hist)))
+        s.close()
+    assert np.allclose(outs[0][1], outs[1][1], rtol=1e-5)
+    assert rel_l2(outs[0][0], outs[1][0]) <= 1e-5
