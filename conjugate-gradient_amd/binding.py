@@ -26,7 +26,7 @@ EXPORTS = [
     "cg_solver_kernel_A", "cg_solver_kernel_B", "cg_solver_r", "cg_solver_p",
     "cg_links_box_bytes", "cg_links_alloc", "cg_links_free", "cg_links_peer_ok", "cg_links_export", "cg_links_open",
     "cg_links_close", "cg_links_poke", "cg_links_peek", "cg_solver_bind_links", "cg_solver_exchange", "cg_solver_links_error",
-    "cg_solver_links_times",
+    "cg_solver_links_times", "cg_noalloc_prepare", "cg_inner_product_noalloc",
 ]
 
 
@@ -170,6 +170,10 @@ class Library:
         c.cg_solver_links_error.restype = i32
         c.cg_solver_links_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         c.cg_solver_links_times.restype = None
+        c.cg_noalloc_prepare.argtypes = []
+        c.cg_noalloc_prepare.restype = i32
+        c.cg_inner_product_noalloc.argtypes = [fp, fp, C.c_ulonglong, fp, vp]
+        c.cg_inner_product_noalloc.restype = i32
 
     # ---- the reference's entry points (main.jl:16-58) --------------------------------
     def conjugate_gradient_gpu(self, b, x, L, d):
@@ -194,6 +198,11 @@ class Library:
         self.c.laplace_gpu_jl(_ptr(ddf), _ptr(u), dx, d, L, N, index_mode, blocks, threads)
 
     # ---- additions -------------------------------------------------------------------
+    def inner_product_noalloc(self, v, w, n, result_dev, stream=None):
+        """Device pointers only; (float) v.w lands in result_dev[0], asynchronously on `stream`.
+        Returns the entry point's status (0 = success)."""
+        return self.c.cg_inner_product_noalloc(_ptr(v), _ptr(w), n, _ptr(result_dev), _ptr(stream))
+
     def strong_scaling_events(self, nblocks, threads_per_block, N, L, d, reps=5):
         return self.c.cg_strong_scaling_events(nblocks, threads_per_block, N, L, d, reps)
 

@@ -336,6 +336,72 @@ extern "C" float time_cpu_laplace(int N, int L, int d)
 
 // =============================== Part 2 ===============================================
 
+// ---- inner product without allocation -----------------------------------------------------------
+// Scratch of cg_inner_product_noalloc: the per-workgroup partial sums of the dot kernel.  Every GPU the
+// library runs on holds its own copy of this array (32 KiB) until the process ends; the name below is
+// only a host-side handle, the device address is looked up once per device.
+static __device__ __align__(256) double scratch[2 * CG_MAX_BLOCKS];
+
+namespace
+{
+constexpr int NOALLOC_MAXDEV = 64;
+double *scratch_of[NOALLOC_MAXDEV] = {nullptr};
+
+// device address of this device's copy of `scratch` (looked up on first use, with that device current)
+int scratch_ptr(double **out)
+{
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess)
+    return (int)e;
+  if (dev < 0 || dev >= NOALLOC_MAXDEV)
+    return (int)hipErrorInvalidDevice;
+  if (!scratch_of[dev])
+  {
+    double *ptr = nullptr;
+    e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+    {
+      fprintf(stderr, "cg_inner_product_noalloc: hipGetSymbolAddress failed on device %d, code: %d, reason: %s\n", dev,
+              (int)e, hipGetErrorString(e));
+      return e != hipSuccess ? (int)e : (int)hipErrorInvalidSymbol;
+    }
+    scratch_of[dev] = ptr;
+  }
+  *out = scratch_of[dev];
+  return 0;
+}
+} // namespace
+
+extern "C" int cg_noalloc_prepare(void)
+{
+  double *ptr = nullptr;
+  return scratch_ptr(&ptr);
+}
+
+extern "C" int cg_inner_product_noalloc(const float *v, const float *w, unsigned long long n, float *result_dev,
+                                        void *stream)
+{
+  if (!v || !w || !result_dev)
+  {
+    fprintf(stderr, "cg_inner_product_noalloc: null pointer argument\n");
+    return (int)hipErrorInvalidValue;
+  }
+  if (n == 0 || n > CG_NOALLOC_MAX_N)
+  {
+    fprintf(stderr, "cg_inner_product_noalloc: n = %llu is outside [1, %llu]\n", n, (unsigned long long)CG_NOALLOC_MAX_N);
+    return (int)hipErrorInvalidValue;
+  }
+  double *part = nullptr;
+  const int e = scratch_ptr(&part);
+  if (e)
+    return e;
+  // every partial the second stage reads is written by the first stage of the same call, so nothing left
+  // in the scratch by an earlier (possibly larger) call is ever read and nothing needs clearing
+  dot_device_into(v, w, n, part, result_dev, (hipStream_t)stream);
+  return 0;
+}
+
 // strong_scaling on the device clock: HIP events around `reps` launches of the caller's shape
 // (after one untimed launch), device-resident data, no host synchronisation inside the window
 extern "C" float cg_strong_scaling_events(int nblocks, int threads_per_block, int N, int L, int d, int reps)

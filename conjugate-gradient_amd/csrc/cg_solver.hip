@@ -1374,6 +1374,31 @@ void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode
   CHECK(hipGetLastError());
 }
 
+// launch shape of the stand-alone dot product: a function of n only, so that two calls on the same
+// vectors add in the same order
+static int dot_grid(unsigned long long n)
+{
+  const unsigned long long nb = (n / 4 + 255) / 256 + 1;
+  return (int)std::min<unsigned long long>(nb, (unsigned long long)max_blocks());
+}
+
+// out[0] = (float) sum(part[0..n)), the value inner_product_gpu returns
+__global__ void __launch_bounds__(64) k_sum_partials_f32(const double *__restrict__ part, int n, float *__restrict__ out)
+{
+  __shared__ double sh[8];
+  const double s = block_read_sum(part, n, sh);
+  if (threadIdx.x == 0)
+    out[0] = (float)s;
+}
+
+void dot_device_into(const float *v, const float *w, unsigned long long n, double *part, float *out_dev, hipStream_t stream)
+{
+  const int grid = dot_grid(n);
+  launch_dot(v, w, n, part, grid, stream);
+  hipLaunchKernelGGL(k_sum_partials_f32, dim3(1), dim3(64), 0, stream, part, grid, out_dev);
+  CHECK(hipGetLastError());
+}
+
 double dot_device(const float *v, const float *w, unsigned long long n, hipStream_t stream)
 {
   // scratch for the partials, one set per device, kept for the life of the process
@@ -1389,8 +1414,7 @@ double dot_device(const float *v, const float *w, unsigned long long n, hipStrea
     CHECK(hipHostMalloc((void **)&host_of[dev], sizeof(double)));
   }
   double *part = part_of[dev], *host = host_of[dev];
-  const unsigned long long nb = (n / 4 + 255) / 256 + 1;
-  const int grid = (int)std::min<unsigned long long>(nb, (unsigned long long)max_blocks());
+  const int grid = dot_grid(n);
   launch_dot(v, w, n, part, grid, stream);
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, stream, part, grid, part + 2 * CG_MAX_BLOCKS);
   CHECK(hipGetLastError());

@@ -158,6 +158,15 @@ void laplace_apply(float *ddf, const float *u, int d, unsigned L, int index_mode
 // deterministic two-stage dot product; returns the double sum
 double dot_device(const float *v, const float *w, unsigned long long n, hipStream_t stream);
 
+// make `s` wait for everything enqueued on the legacy default stream so far (no-op for s == nullptr)
+void order_after_default_stream(hipStream_t s);
+
+// the same dot product with nothing allocated and nothing read back: the per-workgroup partials go to
+// `part` (device memory, at least 2 * CG_MAX_BLOCKS doubles) and (float) of their sum to out_dev[0];
+// asynchronous on `stream`
+void dot_device_into(const float *v, const float *w, unsigned long long n, double *part, float *out_dev,
+                     hipStream_t stream);
+
 void fill_uniform(float *dst, unsigned long long n, unsigned int seed, hipStream_t stream);
 
 } // namespace cgamd

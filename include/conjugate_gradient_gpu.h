@@ -134,6 +134,24 @@ extern "C"
   float cg_strong_scaling_events(int nblocks, int threads_per_block, int N, int L, int d, int reps);
   float cg_laplace_time_events(int L, int d, int index_mode, int reps);
 
+  /* --- an entry point that allocates nothing ------------------------------------------------
+   * No counterpart in the reference.  For callers that cannot allocate device memory: code under
+   * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The same two-stage
+   * dot product as inner_product_gpu (same kernels, same launch shape, same bits), but: v, w must
+   * be device pointers (nothing is staged), the result (float) goes to result_dev[0] in device
+   * memory, the call is asynchronous on `stream` (a hipStream_t, NULL = the default stream) and
+   * neither allocates nor frees nor synchronises.  The per-workgroup partial sums live in a static
+   * 32 KiB device array that every GPU the library is used on holds until the process ends; all
+   * calls on one GPU share it, so calls that overlap in time on one GPU (different streams,
+   * several host threads) race -- keep them on one stream or order them.  n must be in
+   * [1, CG_NOALLOC_MAX_N]; outside that, or with a null pointer, an error is printed to stderr and
+   * a non-zero hipError_t value returned (0 = success).  cg_noalloc_prepare() looks the array's
+   * address up for the current device ahead of time (otherwise the first call on a device does);
+   * call it before a stream capture starts. */
+#define CG_NOALLOC_MAX_N 4294967295ull
+  int cg_noalloc_prepare(void);
+  int cg_inner_product_noalloc(const float *v, const float *w, unsigned long long n, float *result_dev, void *stream);
+
   /* --- solver object: the fused two-kernel iteration on device-resident vectors -------- */
 
   typedef struct cg_solver cg_solver;
