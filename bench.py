@@ -7,31 +7,48 @@
 A step is one CG iteration (kernel A + kernel B) over the whole grid.  Workload at every N:
 each GPU owns an 8192 x 8192 float slab (2^26 points, config "2D Laplace 8192^2 float CG");
 with N > 1 the slabs stack along axis 1 into an 8192 x (8192 N) grid (weak scaling) with one
-halo row of r each way and two dot-product exchanges per iteration: written straight into the
-peers' HBM over xGMI when every rank can map every other rank's box and a three-iteration
-self-check reproduces the collectives' residuals, otherwise over RCCL (config.comm says which).  Synthetic data: b = u01
-(counter-based generator, seed 1234), x0 = 0; float CG cannot converge on this grid within
-any practical count, so every step does full work (the stop tolerance is set to 0).
+halo row of r each way and two dot-product exchanges per iteration (config.comm says which
+transport ran).  Synthetic data: b = u01 (counter-based generator, seed 1234), x0 = 0; float CG
+cannot converge on this grid within any practical count, so every step does full work (the stop
+tolerance is set to 0).
 
-value = slab-iterations per second summed over ranks (= CG iterations/s at N = 1).
-roofline: algorithmic HBM bytes of the dominant kernel (B: 24 B/point) over its mean
-duration measured with HIP events on the solver's stream.  cpu_baseline: the oracle's
-own CPU solver built from its sources (fp64, one core) on a bounded sample, beside the oracle's
-restatement of it.
+Timing: after the warm-up the region "exactly --steps iterations between barrier + synchronize"
+is timed --repeats times in a row on the same running solve (every iteration does full work);
+value and ms_per_step are the MEDIAN region, min and max are printed beside it.
+
+Bytes.  Three prices per grid point, always named:
+  effective  the three-kernel fusion the hot path is specified with: A 20 B (stencil + dot 8, p
+             update 12), B 24 B, iteration 44 B.  roofline.achieved / roofline.frac use this price,
+             so they can exceed the HBM peak: this design never stores A p and reads p once less.
+  moved      what these kernels really stream: A 12 B (r, p_old in, p_new out), B 20 B (x, p, r in,
+             x, r out), iteration 32 B.  frac_moved is the bandwidth the memory system delivers --
+             at 8192^2 part of it from the 256 MiB Infinity Cache, which holds r.
+  counter    bytes leaving L2 per launch, measured in this run by two rocprofv3 --pmc passes
+             (FETCH_SIZE doubled as the gfx950 counter reports half of wide reads, WRITE_SIZE as is);
+             Infinity-Cache hits are included, so it bounds HBM traffic from above.  null when the
+             counter passes could not run.
+cpu_baseline: one CG iteration's worth of the reference's own CPU calls (fp64, one core) on the
+full workload grid where that takes under a minute, else on a bounded cubic sample.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import re
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
-BYTES_A, BYTES_B = 20, 24       # algorithmic bytes/point: A = stencil+dot (8) + p update (12); B = x,r update + dot
-BYTES_ITER = 44
+# bytes per grid point: "effective" = the specified three-kernel fusion, "moved" = what this design streams
+BYTES = {"A": {"effective": 20, "moved": 12}, "B": {"effective": 24, "moved": 20},
+         "iter": {"effective": 44, "moved": 32}}
+BEYOND_CACHE_WORKLOAD = "16384x8192"   # 2^27 points: every vector is twice the Infinity Cache
 
 
 def parse():
@@ -49,6 +66,11 @@ def parse():
                     "self-check, else collectives) | links | collectives")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps iterations; the median is reported")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--no-beyond-cache", action="store_true",
+                    help="skip the second, larger 2-D workload whose vectors exceed the Infinity Cache")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -71,23 +93,153 @@ def workload_extents(name):
     return ext, mode
 
 
-def measured_traffic(workload, kernel_mode):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 counter
-    passes (profiles/*_summary.json, written by tools/summarize_profile.py); None if no
-    profile of this workload is in the tree."""
+def _under_profiler():
+    return any("ROCPROF" in k.upper() or "ROCP_" in k.upper() for k in os.environ) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+
+
+def live_traffic(workload):
+    """Bytes leaving L2 per launch of kernels A and B on `workload`, measured now: two child runs of this
+    script (six plain iterations each) under `rocprofv3 --pmc`, FETCH_SIZE and WRITE_SIZE in separate
+    passes (they do not fit one).  FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of wide
+    coalesced reads at 64 bytes), WRITE_SIZE taken as is; both are in KiB.  Returns ({"A": bytes,
+    "B": bytes}, note); a kernel is missing from the dict when a pass failed."""
+    import csv
     import glob
-    tag = workload.replace("-", "")
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_summary.json")))
-    if not files:
-        return None
-    try:
-        ks = json.load(open(files[-1]))["kernels"]
-        for name, k in ks.items():
-            if any(f"{k}<{kernel_mode}," in name for k in ("k_rows", "k_cols", "k_scalar", "k_planes", "k_morton4", "k_morton_tile")):
-                return k.get("traffic_bytes")
-    except Exception:
-        return None
-    return None
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found", {}
+    if _under_profiler():
+        return {}, "already running under a profiler", {}
+    got = {"fetch": {}, "write": {}}
+    notes = []
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        out = tempfile.mkdtemp(prefix=f"cg_pmc_{kind}_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", workload]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
+            if r.returncode != 0:
+                notes.append(f"{counter} pass exit {r.returncode}: {r.stderr[-200:]}")
+                continue
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            per = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    m = re.search(r"cgamd::k_\w+<(\d),", row.get("Kernel_Name", ""))
+                    if m and m.group(1) in "12" and row.get("Counter_Name", counter) == counter:
+                        per.setdefault("A" if m.group(1) == "1" else "B", []).append(float(row["Counter_Value"]))
+            for k, v in per.items():
+                full = [x for x in v if x > 0.5 * max(v)]   # drop no-op launches
+                got[kind][k] = statistics.median(full) * 1024.0 * (2.0 if kind == "fetch" else 1.0)
+            if not per:
+                notes.append(f"{counter} pass: no kernel rows")
+        except Exception as e:  # noqa: BLE001 -- the counters are optional evidence, never fatal
+            notes.append(f"{counter} pass failed: {e!r}"[:300])
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    traffic = {k: int(got["fetch"][k] + got["write"][k]) for k in ("A", "B") if k in got["fetch"] and k in got["write"]}
+    detail = {k: {"fetch_bytes": int(got["fetch"][k]), "write_bytes": int(got["write"][k])} for k in traffic}
+    return traffic, ("; ".join(notes) if notes else "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run, "
+                     "6 plain iterations each; FETCH_SIZE x2 (gfx950), Infinity-Cache hits included"), detail
+
+
+def pmc_child(args):
+    """What the counter passes profile: the solver on the workload, six plain (un-graphed) iterations."""
+    import torch
+    from __graft_entry__ import load_package
+    lib = load_package().load_library()
+    ext, mode = workload_extents(args.workload)
+    N = 1
+    for e in ext:
+        N *= e
+    b = torch.empty(N, dtype=torch.float32, device="cuda")
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(C.c_void_p(b.data_ptr()), N, 1234)
+    torch.cuda.synchronize()
+    s = lib.make_solver(ext, index_mode=mode)
+    s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+    s.iterate(6, use_graph=False)
+    s.sync()
+    s.finish()
+    s.close()
+
+
+def run_single(lib, ext, mode, steps, warmup, repeats, graph, barrier, device):
+    """The timed regions on one GPU: warm-up, then `repeats` regions of exactly `steps` iterations of
+    the same running solve, then the per-kernel event timing.  Returns a dict."""
+    import torch
+    N = 1
+    for e in ext:
+        N *= e
+    b = torch.empty(N, dtype=torch.float32, device=device)
+    x = torch.zeros(N, dtype=torch.float32, device=device)
+    lib.c.cg_fill_uniform(C.c_void_p(b.data_ptr()), N, 1234)
+    torch.cuda.synchronize()
+    s = lib.make_solver(ext, index_mode=mode)
+    s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+    s.iterate(warmup, use_graph=graph)
+    s.sync()
+    times = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        s.iterate(steps, use_graph=graph)
+        s.sync()
+        barrier()
+        times.append(time.perf_counter() - t0)
+    done, res, _ = s.finish()
+    assert done == warmup + steps * repeats, (done, warmup, steps, repeats)
+    # per-kernel device time: HIP events on the solver's stream, outside the timed regions
+    msA, msB = s.time_kernels(max(10, min(50, steps)))
+    name = s.kernel_name
+    s.close()
+    del b, x
+    return {"N": N, "times": times, "msA": msA, "msB": msB, "kernel": name, "residue": res}
+
+
+def roofline_of(run, traffic=None, traffic_note=None, traffic_detail=None):
+    """The roofline object of the dominant kernel of one run_single() result."""
+    N, msA, msB = run["N"], run["msA"], run["msB"]
+    dom, other = ("B", "A") if msB >= msA else ("A", "B")
+    ms = {"A": msA, "B": msB}
+
+    def rate(k, price):
+        return BYTES[k][price] * N / (ms[k] * 1e-3) / 1e9
+
+    eff, mov = rate(dom, "effective"), rate(dom, "moved")
+    roof = {"bound": "hbm", "kernel": run["kernel"] + f"<MODE_{dom}>",
+            "achieved": round(eff, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(eff / HBM_PEAK_GBPS, 4),
+            "pricing": f"effective: {BYTES[dom]['effective']} B/point of the specified three-kernel fusion; this kernel "
+                       f"streams {BYTES[dom]['moved']} B/point (see frac_moved), so the effective figure can exceed the peak",
+            "frac_effective": round(eff / HBM_PEAK_GBPS, 4),
+            "achieved_moved": round(mov, 1), "frac_moved": round(mov / HBM_PEAK_GBPS, 4),
+            "moved_bytes_per_point": BYTES[dom]["moved"],
+            "traffic": (traffic or {}).get(dom), "traffic_note": traffic_note,
+            "algorithmic_bytes": BYTES[dom]["effective"] * N,
+            "algorithmic_bytes_per_point": BYTES[dom]["effective"], "ms_per_launch": round(ms[dom], 5),
+            "other_kernel": {"kernel": f"MODE_{other}", "ms_per_launch": round(ms[other], 5),
+                             "achieved_effective": round(rate(other, "effective"), 1),
+                             "achieved_moved": round(rate(other, "moved"), 1),
+                             "frac_moved": round(rate(other, "moved") / HBM_PEAK_GBPS, 4),
+                             "traffic": (traffic or {}).get(other)}}
+    if traffic and dom in traffic:
+        roof["achieved_counter"] = round(traffic[dom] / (ms[dom] * 1e-3) / 1e9, 1)
+        roof["frac_counter"] = round(roof["achieved_counter"] / HBM_PEAK_GBPS, 4)
+        roof["traffic_over_moved"] = round(traffic[dom] / (BYTES[dom]["moved"] * N), 4)
+    if traffic_detail:
+        roof["traffic_detail"] = traffic_detail
+    return roof
+
+
+def iteration_rates(N, its):
+    """Whole-iteration byte rates of `its` iterations/s on N points, both prices."""
+    eff = BYTES["iter"]["effective"] * N * its / 1e9
+    mov = BYTES["iter"]["moved"] * N * its / 1e9
+    return {"hbm_effective_GBps": round(eff, 1), "hbm_frac_effective": round(eff / HBM_PEAK_GBPS, 4),
+            "hbm_moved_GBps": round(mov, 1), "hbm_frac_moved": round(mov / HBM_PEAK_GBPS, 4)}
 
 
 def cpu_baseline_c1():
@@ -106,49 +258,62 @@ def cpu_baseline_c1():
 
 
 def cpu_baseline(ext, budget_s):
-    """The reference's own conjugate_gradient (conjugate-gradient_cpu.cu:216-261, fp64, one thread),
-    compiled unchanged from its sources with its -O3 (oracle/_ref/libcg_ref_opt.so), on a bounded
-    sample: a square/cubic grid of the workload's dimension sized so that the solve to the
-    reference's own tolerance takes roughly budget_s / 2.  That function has no iteration counter;
-    the count comes from the oracle's restatement run on the same input, which is also timed
-    ("port") and whose solution must equal the reference's bit for bit.  iterations/s is scaled to
-    the workload's point count (cost per iteration is linear in points).  Without the reference
-    build the port alone is reported."""
+    """One CG iteration's worth of the reference's own CPU calls, timed on one core: minus_laplace
+    (conjugate-gradient_cpu.cu:97-113) once and inner_product (:150-158) twice from the reference's
+    sources compiled unchanged with its -O3 (oracle/_ref/libcg_ref_opt.so), plus the three vector
+    updates of its loop (:241-252) as numpy expressions (they are inline statements of
+    conjugate_gradient, which has no iteration cap and cannot be stopped after one iteration).
+    On the workload's own grid when that is a cube/square whose estimated time is under about
+    3 x budget_s; otherwise on a cubic sample of the same dimension sized for budget_s, scaled by
+    points (the cost per iteration is linear in points).  Without the reference build the oracle's
+    restatement of the same functions is timed instead (kind "port")."""
     import numpy as np
     from oracle import oracle as orc
-    o = orc.Oracle(native=True)
+    ref = orc.Reference(native=True)
+    kind = "reference" if ref.available else "port"
+    lib = ref.lib if ref.available else orc.Oracle(native=True).lib
+    lap = lib.ref_minus_laplace if ref.available else lib.orc_minus_laplace
+    dot = lib.ref_inner_product if ref.available else lib.orc_inner_product
     d = len(ext)
     n_full = 1
     for e in ext:
         n_full *= e
-    # calibrate on a small grid: iterations grow like L, cost per iteration like L^d
-    L0 = {1: 192, 2: 64, 3: 20, 4: 10}.get(d, 6)
-    b0 = np.random.default_rng(0).random(L0 ** d)
-    t0 = time.perf_counter()
-    o.conjugate_gradient(b0, L0, d)
-    t_cal = max(time.perf_counter() - t0, 1e-4)
-    L = int(L0 * (0.5 * budget_s / t_cal) ** (1.0 / (d + 1)))
-    L = max(L0, min(L, min(ext)))
-    n = L ** d
-    b = np.random.default_rng(1).random(n)
-    t0 = time.perf_counter()
-    x_port, _, done, _ = o.conjugate_gradient(b, L, d)
-    dt_port = time.perf_counter() - t0
-    scale = n / n_full
-    port = {"value": done / dt_port * scale, "unit": "iterations/s", "cores": 1, "kind": "port", "L": L,
-            "sample": f"{done} fp64 CG iterations to 1e-6 on a {L}^{d} grid ({n} points, {dt_port:.1f} s), "
-                      f"scaled by points to the {'x'.join(map(str, ext))} workload"}
-    ref = orc.Reference(native=True)
-    if not ref.available:
-        return port
-    t0 = time.perf_counter()
-    x_ref, _ = ref.conjugate_gradient(b, L, d)
-    dt_ref = time.perf_counter() - t0
-    return {"value": done / dt_ref * scale, "unit": "iterations/s", "cores": 1, "kind": "reference",
-            "sample": f"the reference's conjugate_gradient to its 1e-6 tolerance on a {L}^{d} grid ({n} points): "
-                      f"{done} iterations in {dt_ref:.1f} s, scaled by points to the {'x'.join(map(str, ext))} workload",
-            "bit_identical_to_port": bool(np.array_equal(x_ref, x_port)),
-            "port": port}
+
+    def one_iteration(L):
+        n = L ** d
+        rng = np.random.default_rng(1)
+        p = np.zeros(n + 1)
+        p[:n] = rng.random(n)
+        r = np.zeros(n + 1)
+        r[:n] = rng.random(n)
+        x = np.zeros(n + 1)
+        Ap = np.zeros(n + 1)
+        t0 = time.perf_counter()
+        lap(Ap, p, d, L, n)                       # Ap = A p
+        t_lap = time.perf_counter() - t0
+        rr = float(n) / 3.0                        # the loop carries r.r over from the previous iteration
+        alpha = rr / dot(p, Ap, n)                # :243
+        x[:n] += alpha * p[:n]                    # :244-247
+        r[:n] -= alpha * Ap[:n]
+        beta = dot(r, r, n) / rr                  # :248-249
+        p[:n] = r[:n] + beta * p[:n]
+        return time.perf_counter() - t0, t_lap, n
+
+    L0 = {1: 1 << 16, 2: 256, 3: 40, 4: 16}.get(d, 8)
+    t_cal, _, n_cal = one_iteration(L0)
+    per_point = t_cal / n_cal
+    cubic = all(e == ext[0] for e in ext)
+    if cubic and per_point * n_full <= 3.0 * budget_s:
+        L = ext[0]
+    else:
+        L = max(L0, min(int((budget_s / per_point) ** (1.0 / d)), min(ext)))
+    t_it, t_lap, n = one_iteration(L)
+    where = ("the workload's own grid" if n == n_full else
+             f"a {L}^{d} sample ({n} points), scaled by points to the {'x'.join(map(str, ext))} workload")
+    return {"value": 1.0 / t_it * n / n_full, "unit": "iterations/s", "cores": 1, "kind": kind, "L": L,
+            "sample": f"one CG iteration's worth of calls (1 minus_laplace {t_lap:.1f} s, 2 inner_product, 3 vector "
+                      f"updates; {t_it:.1f} s in all, fp64) on {where}",
+            "measured_at_full_size": n == n_full}
 
 
 def cpu_baseline_all_cores(ext, L):
@@ -186,9 +351,9 @@ def cpu_baselines_isolated(ext, budget_s):
     import subprocess
     code = ("import json,sys; sys.path.insert(0, %r); import bench; "
             "cb = bench.cpu_baseline(%r, %r); "
-            "L = cb.get('L') or cb.get('port', {}).get('L'); "
+            "L = {1: 1 << 18, 2: 320, 3: 48, 4: 16}.get(len(%r), 8); "
             "print(json.dumps({'cpu_baseline': cb, 'cpu_baseline_all_cores': bench.cpu_baseline_all_cores(%r, L), "
-            "'cpu_baseline_1d_2e20': bench.cpu_baseline_c1()}))" % (ROOT, list(ext), float(budget_s), list(ext)))
+            "'cpu_baseline_port_1d_2e20': bench.cpu_baseline_c1()}))" % (ROOT, list(ext), float(budget_s), list(ext), list(ext)))
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
         if r.returncode == 0:
@@ -233,47 +398,41 @@ def main():
     for e in ext:
         N *= e
 
-    b = torch.empty(N, dtype=torch.float32, device=device)
-    x = torch.zeros(N, dtype=torch.float32, device=device)
-    # rank-distinct synthetic right-hand side: one global u01 stream cut into slabs
-    lib.c.cg_fill_uniform(C.c_void_p(b.data_ptr()), N, 1234 + rank)
-    torch.cuda.synchronize()
-
     def barrier():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
     roof = None
-    if world == 1 and not args.force_slab:
-        s = lib.make_solver(ext, index_mode=mode)
-        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
-        s.iterate(args.warmup, use_graph=not args.no_graph)
-        s.sync()
-        barrier()
-        t0 = time.perf_counter()
-        s.iterate(args.steps, use_graph=not args.no_graph)
-        s.sync()
-        barrier()
-        dt = time.perf_counter() - t0
-        done, res, _ = s.finish()
-        assert done == args.warmup + args.steps, (done, args.warmup, args.steps)
-        # per-kernel device time, HIP events on the solver's stream, outside the timed region
-        msA, msB = s.time_kernels(max(10, min(50, args.steps)))
-        gA = BYTES_A * N / (msA * 1e-3) / 1e9
-        gB = BYTES_B * N / (msB * 1e-3) / 1e9
-        dom = ("B", msB, gB, BYTES_B) if msB >= msA else ("A", msA, gA, BYTES_A)
-        roof = {"bound": "hbm", "kernel": s.kernel_name + f"<MODE_{dom[0]}>",
-                "achieved": round(dom[2], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(dom[2] / HBM_PEAK_GBPS, 4),
-                "traffic": measured_traffic(args.workload, 2 if dom[0] == "B" else 1),
-                "algorithmic_bytes": dom[3] * N,
-                "algorithmic_bytes_per_point": dom[3], "ms_per_launch": round(dom[1], 5),
-                "other_kernel": {"ms_per_launch": round(msA if dom[0] == "B" else msB, 5),
-                                 "achieved": round(gA if dom[0] == "B" else gB, 1)}}
+    extra = {}
+    single = world == 1 and not args.force_slab
+    if single:
+        run = run_single(lib, ext, mode, args.steps, args.warmup, args.repeats, not args.no_graph, barrier, device)
+        times, res = run["times"], run["residue"]
+        traffic, tnote, tdetail = ({}, "counter passes skipped (--no-traffic)", {}) if args.no_traffic else live_traffic(args.workload)
+        roof = roofline_of(run, traffic, tnote, tdetail)
+        if not args.no_beyond_cache and args.workload == "2d-8192":
+            # the same kernels on a 2-D grid whose vectors are twice the Infinity Cache: the HBM-bound rate
+            ext2, mode2 = workload_extents(BEYOND_CACHE_WORKLOAD)
+            run2 = run_single(lib, ext2, mode2, args.steps, args.warmup, max(3, args.repeats // 2 + 1), not args.no_graph,
+                              barrier, device)
+            t2 = statistics.median(run2["times"])
+            its2 = args.steps / t2
+            extra["beyond_cache"] = dict(
+                {"workload": BEYOND_CACHE_WORKLOAD, "points": run2["N"], "iterations_per_sec": round(its2, 3),
+                 "ms_per_step": round(t2 / args.steps * 1e3, 5),
+                 "ms_per_step_min_max": [round(min(run2["times"]) / args.steps * 1e3, 5),
+                                         round(max(run2["times"]) / args.steps * 1e3, 5)],
+                 "roofline": roofline_of(run2, None, "not collected for this workload")},
+                **iteration_rates(run2["N"], its2))
         parallelism = "single"
     else:
         from conjugate_gradient_amd.slab import SlabCG
+        b = torch.empty(N, dtype=torch.float32, device=device)
+        x = torch.zeros(N, dtype=torch.float32, device=device)
+        # rank-distinct synthetic right-hand side
+        lib.c.cg_fill_uniform(C.c_void_p(b.data_ptr()), N, 1234 + rank)
+        torch.cuda.synchronize()
         s = SlabCG(lib, ext, rank=rank, world=world, device=device)
         comm, comm_note = "collectives", ""
 
@@ -340,20 +499,22 @@ def main():
             s.begin(b, x, 0.0, 1)
             s.iterate(args.warmup)
             s.sync()
-            barrier()
-            t0 = time.perf_counter()
-            s.iterate(args.steps)
-            s.sync()
-            barrier()
-            dt = time.perf_counter() - t0
+            ts = []
+            for _ in range(args.repeats):
+                barrier()
+                t0 = time.perf_counter()
+                s.iterate(args.steps)
+                s.sync()
+                barrier()
+                ts.append(time.perf_counter() - t0)
             done, res, _ = s.finish()
-            if done != args.warmup + args.steps:
-                raise RuntimeError(f"{done} iterations ran instead of {args.warmup + args.steps}")
-            return dt, res
+            if done != args.warmup + args.steps * args.repeats:
+                raise RuntimeError(f"{done} iterations ran instead of {args.warmup + args.steps * args.repeats}")
+            return ts, res
 
         ok = 1
         try:
-            dt, res = timed()
+            times, res = timed()
         except RuntimeError as e:
             if comm != "xgmi-links":
                 raise
@@ -362,7 +523,7 @@ def main():
             # a rank lost the direct path under load: everyone goes back to the collectives
             s.disable_links()
             comm = "collectives"
-            dt, res = timed()
+            times, res = timed()
         parallelism = f"slab{world}"
         if comm == "xgmi-links":
             with s._ctx():
@@ -381,16 +542,17 @@ def main():
             msA, msB = t.time_kernels(max(10, min(50, args.steps)))
             t.close()
             exchange = None
-        gB = BYTES_B * N / (msB * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "MODE_B", "achieved": round(gB, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(gB / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.workload, 2),
-                "algorithmic_bytes": BYTES_B * N, "ms_per_launch": round(msB, 5),
-                "other_kernel": {"ms_per_launch": round(msA, 5)}, "exchange_ms": exchange, "rank": 0}
+        roof = roofline_of({"N": N, "msA": msA, "msB": msB, "kernel": s.ops.solver.kernel_name}, None,
+                           "not collected in multi-rank runs")
+        roof["exchange_ms"] = exchange
+        roof["rank"] = 0
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+    # every region's time is the maximum over ranks; the median region is reported
+    tmax = torch.tensor(times, dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    times = [float(v) for v in tmax.tolist()]
+    dt = statistics.median(times)
 
     if rank == 0:
         its = args.steps / dt
@@ -407,11 +569,14 @@ def main():
                        "backend": args.backend if world > 1 else None,
                        "comm": (comm + (f" ({comm_note})" if comm_note else "")) if parallelism != "single" else None,
                        "rhs": "u01 seed 1234+rank", "x0": 0},
+            "timing": {"regions": args.repeats, "statistic": "median",
+                       "ms_per_step_min_max": [round(min(times) / args.steps * 1e3, 5), round(max(times) / args.steps * 1e3, 5)],
+                       "ms_per_step_all": [round(t / args.steps * 1e3, 5) for t in times]},
             "iterations_per_sec_global": round(its, 3),
-            "hbm_algorithmic_GBps": round(BYTES_ITER * N * world * its / 1e9, 1),
-            "hbm_frac_of_peak": round(BYTES_ITER * N * its / 1e9 / HBM_PEAK_GBPS, 4),
             "final_residue": res,
         }
+        out.update(iteration_rates(N * world, its))   # all ranks' points move once per global iteration
+        out.update(extra)
         if roof:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
@@ -423,4 +588,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--pmc-child" in sys.argv:
+        pmc_child(parse())
+    else:
+        main()

@@ -223,7 +223,11 @@ class Library:
         """b, x: addresses of N doubles (host or device). Returns (outer_iterations, [inner steps])."""
         inner = (C.c_int * 1002)()
         outer = self.c.preconditioned_cg_gpu(_ptr(b), _ptr(x), L, d, C.cast(inner, C.c_void_p), 1002, verbose)
-        return outer, [v for v in inner if v][:outer + 1] if outer else []
+        # one preconditioner call before the loop and one per outer iteration that did not stop on the
+        # tolerance (conjugate-gradient_cpu.cu:348,374-376); the library ends the list with -1 because a
+        # legitimate count can be 0
+        counts = list(inner)
+        return outer, counts[:counts.index(-1)] if -1 in counts else counts
 
     def eigen_extremes_gpu(self, L, d, max_steps=1000, tol=1e-7, seed=1, want_max=True, want_min=True):
         """Returns dict(lambda_max, steps_max, lambda_min, steps_min, cg_iterations) of the L^d operator."""

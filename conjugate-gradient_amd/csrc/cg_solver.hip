@@ -517,6 +517,8 @@ Solver::~Solver()
   (void)hipStreamSynchronize(stream_);
   if (graph_)
     (void)hipGraphExecDestroy(graph_);
+  if (tail_graph_)
+    (void)hipGraphExecDestroy(tail_graph_);
   if (own_r_)
     (void)hipFree(r_base_);
   if (own_p0_)
@@ -992,14 +994,33 @@ void Solver::copy_rows(float *dst, size_t dpitch, const float *src, size_t spitc
                          hipMemcpyDeviceToDevice, stream_));
 }
 
+// The reference does everything on the legacy default stream, so whatever produced b and x there (add_jl,
+// a copy, another library's kernels on stream 0) is implicitly ordered before its solve.  A private
+// non-blocking stream has no such ordering: make it wait for what the default stream holds right now.
+void order_after_default_stream(hipStream_t s)
+{
+  if (!s)
+    return;
+  constexpr int MAXDEV = 64;
+  static hipEvent_t ev_of[MAXDEV] = {nullptr};
+  int dev = 0;
+  CHECK(hipGetDevice(&dev));
+  CG_REQUIRE(dev >= 0 && dev < MAXDEV, "device ordinal out of range");
+  if (!ev_of[dev])
+    CHECK(hipEventCreateWithFlags(&ev_of[dev], hipEventDisableTiming));
+  CHECK(hipEventRecord(ev_of[dev], nullptr));
+  CHECK(hipStreamWaitEvent(s, ev_of[dev], 0));
+}
+
 void Solver::begin_local(const float *b_dev, float *x_dev)
 {
+  if (own_stream_)
+    order_after_default_stream(stream_);
+  hist_all_.clear();
+  hist_seen_ = 0;
   x_ = x_dev;
-  if (graph_ && !pad_ && !relay_ && graph_x_ != x_dev)
-  {
-    CHECK(hipGraphExecDestroy(graph_));
-    graph_ = nullptr;
-  }
+  if ((graph_ || tail_graph_) && !pad_ && !relay_ && graph_x_ != x_dev)
+    drop_graphs();
   if (pad_)
   {
     x_user_ = x_dev;
@@ -1033,11 +1054,7 @@ void Solver::bind_sums(const double *sumA, int nA, const double *sumB, int nB)
   nA_ = sumA ? nA : grid_;
   sumB_ = sumB ? sumB : partB_;
   nB_ = sumB ? nB : grid_;
-  if (graph_)
-  {
-    CHECK(hipGraphExecDestroy(graph_));
-    graph_ = nullptr;
-  }
+  drop_graphs();
 }
 
 void Solver::bind_partials(double *partA, double *partB)
@@ -1201,23 +1218,53 @@ void Solver::iterate(int n, bool use_graph)
       launch_iteration();
     return;
   }
-  if (!graph_ || graph_iters_ != chunk)
-  {
-    if (graph_)
-      CHECK(hipGraphExecDestroy(graph_));
+  // whole chunks replay one captured graph; what is left over replays a second, shorter graph, so that
+  // exactly n iterations are launched (iterations beyond maxit would be device-side no-ops, but each
+  // still costs a launch)
+  auto capture = [&](int iters) {
     hipGraph_t g;
+    hipGraphExec_t ge;
     CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < chunk; i++)
+    for (int i = 0; i < iters; i++)
       launch_iteration();
     CHECK(hipStreamEndCapture(stream_, &g));
-    CHECK(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
+    CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     CHECK(hipGraphDestroy(g));
+    return ge;
+  };
+  if (n >= chunk && (!graph_ || graph_iters_ != chunk))
+  {
+    drop_graphs();
+    graph_ = capture(chunk);
     graph_iters_ = chunk;
     graph_x_ = x_;
   }
-  // iterations beyond maxit are device-side no-ops, so whole chunks are always safe
-  for (int done = 0; done < n; done += chunk)
+  int left = n;
+  for (; left >= chunk; left -= chunk)
     CHECK(hipGraphLaunch(graph_, stream_));
+  if (left > 0)
+  {
+    if (!tail_graph_ || tail_iters_ != left || graph_x_ != x_)
+    {
+      if (tail_graph_)
+        CHECK(hipGraphExecDestroy(tail_graph_));
+      tail_graph_ = capture(left);
+      tail_iters_ = left;
+      graph_x_ = x_;
+    }
+    CHECK(hipGraphLaunch(tail_graph_, stream_));
+  }
+}
+
+void Solver::drop_graphs()
+{
+  if (graph_)
+    CHECK(hipGraphExecDestroy(graph_));
+  if (tail_graph_)
+    CHECK(hipGraphExecDestroy(tail_graph_));
+  graph_ = nullptr;
+  tail_graph_ = nullptr;
+  graph_iters_ = tail_iters_ = 0;
 }
 
 void Solver::run(int maxit, bool use_graph, int poll)
@@ -1242,6 +1289,14 @@ void Solver::read_state(CgState *host_copy)
   CHECK(hipMemcpyAsync(st_host_, st_, sizeof(CgState), hipMemcpyDeviceToHost, stream_));
   CHECK(hipStreamSynchronize(stream_));
   *host_copy = *st_host_;
+  // keep every r.r the device ring still holds: a solve longer than the ring is polled (run()) more
+  // often than the ring wraps, so the host copy ends up complete
+  const int n = st_host_->itA;
+  if ((int)hist_all_.size() < n)
+    hist_all_.resize((size_t)n, NAN);
+  for (int i = std::max(hist_seen_, n - CG_HIST + 1); i < n; i++)
+    hist_all_[(size_t)i] = st_host_->rr_hist[i % CG_HIST];
+  hist_seen_ = std::max(hist_seen_, n);
 }
 
 int Solver::finish(float *residue, float *hist, int hist_len)
@@ -1260,9 +1315,10 @@ int Solver::finish(float *residue, float *hist, int hist_len)
     *residue = (float)sqrt((double)s.rr_hist[last % CG_HIST]);
   if (hist)
   {
-    // hist[i] = value printed after iteration i+1 (:369); only the last CG_HIST are kept
+    // hist[i] = value printed after iteration i+1 (:369); NaN where the device ring was overwritten
+    // before the host saw it (more than CG_HIST iterations enqueued without a run() poll or finish())
     for (int i = 0; i < n && i < hist_len; i++)
-      hist[i] = (n - i < CG_HIST) ? (float)sqrt((double)s.rr_hist[i % CG_HIST]) : NAN;
+      hist[i] = (float)sqrt((double)hist_all_[(size_t)i]);
   }
   return n;
 }

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include <vector>
+
 #include "cg_device.hpp"
 #include "cg_links.hpp"
 #include "cg_morton.hpp"
@@ -146,8 +148,11 @@ private:
   LinkArgs links_{};
   LinkCtl *link_ctl_ = nullptr;
   float ms_xA_ = 0, ms_xB_ = 0;
-  hipGraphExec_t graph_ = nullptr;
-  int graph_iters_ = 0;
+  hipGraphExec_t graph_ = nullptr, tail_graph_ = nullptr; // a chunk of iterations; the remainder of a request
+  int graph_iters_ = 0, tail_iters_ = 0;
+  void drop_graphs();
+  std::vector<float> hist_all_; // r.r of every iteration the host has seen so far (read_state)
+  int hist_seen_ = 0;
   float *graph_x_ = nullptr;
 };
 

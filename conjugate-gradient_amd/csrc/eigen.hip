@@ -43,6 +43,7 @@ extern "C" int cg_eigen_extremes_gpu(int L, int d, int max_steps, double tol, un
     desc.extents[k] = (unsigned)L;
   Solver cg(desc);
   hipStream_t s = cg.stream();
+  order_after_default_stream(s);
   float *q, *z;
   CHECK(hipMalloc((void **)&q, N * sizeof(float)));
   CHECK(hipMalloc((void **)&z, N * sizeof(float)));

@@ -151,6 +151,7 @@ extern "C" int preconditioned_cg_gpu(const double *b, double *x, int L, int d, i
     desc.extents[k] = (unsigned)L;
   Solver inner(desc);
   hipStream_t s = inner.stream();
+  order_after_default_stream(s); // the caller's b and x may come from work on the default stream
 
   Mixed m;
   m.s = s;
@@ -227,6 +228,8 @@ extern "C" int preconditioned_cg_gpu(const double *b, double *x, int L, int d, i
   }
   CHECK(hipGetLastError());
   CHECK(hipStreamSynchronize(s));
+  if (inner_iters && ncalls < inner_len)
+    inner_iters[ncalls] = -1; // terminator: a legitimate count can be 0
   if (verbose)
     printf("number of steps (outer) %i\n", it);
   if (!x_dev)

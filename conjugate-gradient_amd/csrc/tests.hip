@@ -136,9 +136,41 @@ static void test_cpu_side()
   assert(inner_product(x, y, 3) == 32);
 }
 
+// neighbour_index_gpu is __host__ __device__ in the reference (conjugate-gradient_gpu.cuh:16-18): a caller's
+// kernel calls the device side, the host calls the library's export, and both must agree everywhere
+__global__ void neighbours_on_device(unsigned int *out, unsigned int L, unsigned int d, unsigned int N, int index_mode)
+{
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N)
+    return;
+  for (unsigned int k = 0; k < d; k++)
+    for (int a = -1; a <= 1; a++)
+      out[(i * d + k) * 3 + (a + 1)] = neighbour_index_gpu(i, (int)k, a, L, d, N, index_mode);
+}
+
+static void test_neighbour_index_device(unsigned int L, unsigned int d, int index_mode)
+{
+  unsigned int N = 1;
+  for (unsigned int k = 0; k < d; k++)
+    N *= L;
+  unsigned int *out;
+  OK(hipMallocManaged((void **)&out, (size_t)N * d * 3 * sizeof(unsigned int)));
+  neighbours_on_device<<<(N + 255) / 256, 256>>>(out, L, d, N, index_mode);
+  OK(hipDeviceSynchronize());
+  for (unsigned int i = 0; i < N; i++)
+    for (unsigned int k = 0; k < d; k++)
+      for (int a = -1; a <= 1; a++)
+        assert(out[(i * d + k) * 3 + (a + 1)] == neighbour_index_gpu(i, (int)k, a, L, d, N, index_mode));
+  OK(hipFree(out));
+}
+
 int main()
 {
   test_cpu_side();
+  test_neighbour_index_device(5, 3, 0);
+  test_neighbour_index_device(10, 2, 1);
+  test_neighbour_index_device(8, 3, 2);
+  test_neighbour_index_device(4, 4, 2);
   assert(neighbour_index_gpu(2, 1, 1, 3, 2, 9, 0) == 5);
   assert(neighbour_index_gpu(2, 0, 1, 3, 2, 9, 0) == 9);
   assert(neighbour_index_gpu(3, 0, -1, 3, 2, 9, 0) == 9);

@@ -285,6 +285,7 @@ extern "C" int cg_two_grid_gpu(const float *f, float *u, int L, int d, int nu1, 
 {
   CG_REQUIRE(max_cycles >= 0, "cycles must not be negative");
   TwoGrid tg(L, d, nu1, nu2, omega, coarse_rel);
+  order_after_default_stream(tg.s);
   const double tol = rel * sqrt(dot_device(f, f, tg.N, tg.s));
   int cycles = 0;
   double res = tg.residual_norm(u, f);
@@ -312,6 +313,7 @@ extern "C" int cg_multigrid_gpu(const float *f, float *u, int L, int d, int leve
 {
   CG_REQUIRE(max_cycles >= 0 && levels >= 0 && levels != 1, "cycles must not be negative; levels is 0 or at least 2");
   TwoGrid mg(L, d, nu1, nu2, omega, coarse_rel, levels == 0 ? 64 : levels);
+  order_after_default_stream(mg.s);
   const double tol = rel * sqrt(dot_device(f, f, mg.N, mg.s));
   int cycles = 0;
   double res = mg.residual_norm(u, f);
@@ -343,6 +345,7 @@ extern "C" int cg_two_grid_pcg_gpu(const float *f, float *u, int L, int d, int n
   TwoGrid tg(L, d, nu, nu, omega, coarse_rel);
   const unsigned long long N = tg.N;
   hipStream_t s = tg.s;
+  order_after_default_stream(s);
   float *r, *z, *p, *q;
   CHECK(hipMalloc((void **)&r, N * sizeof(float)));
   CHECK(hipMalloc((void **)&z, N * sizeof(float)));

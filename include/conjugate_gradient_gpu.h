@@ -81,8 +81,8 @@ extern "C"
    * inner solve, the scheme the reference's readme.md:81 describes): outer CG in double
    * to 1e-8*|b| (cap 1000), M^-1 r by conjugate_gradient_gpu_ex(rel 1e-3, fresh-residual
    * rule).  b, x: N doubles, host or device; x is the initial guess and the result.
-   * Returns the number of outer iterations; inner_iters (inner_len ints) receives the
-   * inner step counts. */
+   * Returns the number of outer iterations; inner_iters (inner_len ints, may be NULL) receives
+   * the inner step counts of the preconditioner calls in order, followed by -1 if there is room. */
   int preconditioned_cg_gpu(const double *b, double *x, int L, int d, int *inner_iters, int inner_len,
                             int verbose);
 

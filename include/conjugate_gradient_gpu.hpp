@@ -31,3 +31,37 @@ float norm(float *v, int N);
 
 // conjugate-gradient_gpu.cuh:50 -- glibc rand()/RAND_MAX fill through a host-visible pointer
 float *random_array(float *r, int L, int d, int N);
+
+// conjugate-gradient_gpu.cuh:16-18 declares neighbour_index_gpu __host__ __device__.  The host side is the
+// library's exported symbol (conjugate_gradient_gpu.h); this is its device-side twin for a caller's own
+// kernels: the same rule, inline (device code cannot link against a shared object).  Lexicographic
+// (index_mode 0, 1): the step leaves the grid when the coordinate, kept in an unsigned, wraps to -1 or
+// reaches L (conjugate-gradient_gpu.cu:131-146).  Morton (index_mode 2): masked increment / decrement of
+// the coordinate's bits (interleave.cuh:43-67), N for a step out of the 2^(m d)-point grid.
+extern "C" __device__ inline unsigned int neighbour_index_gpu(unsigned int ind, int direction, int amount, unsigned int L,
+                                                              unsigned int d, unsigned int N, int index_mode)
+{
+  if (index_mode == 2)
+  {
+    if (amount == 0)
+      return ind;
+    unsigned int base = 0;
+    for (unsigned int i = 0; i < 32; i += d)
+      base = (base << d) + 1u;
+    const unsigned int mask = base << direction, cm = mask & (N - 1u);
+    if (amount > 0)
+      return (ind & cm) == cm ? N : ((ind & ~mask) | ((((ind & mask) | ~mask) + 1u) & mask));
+    return (ind & cm) == 0u ? N : ((ind & ~mask) | (((ind & mask) - 1u) & mask));
+  }
+  unsigned int cord = ind;
+  int n = 1;
+  for (int i = 0; i < direction; i++)
+  {
+    cord /= L;
+    n *= (int)L;
+  }
+  cord = cord % L + (unsigned int)amount;
+  if (cord == 0xffffffffu || cord == L)
+    return N;
+  return ind + (unsigned int)(amount * n);
+}

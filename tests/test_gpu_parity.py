@@ -489,6 +489,27 @@ def test_strong_scaling_and_cpu_timer_return_microseconds(lib):
     assert 0 < t2 < 1e6
 
 
+def test_event_timers_of_the_stencil(lib):
+    """strong_scaling (julia.cu:16-30) re-based on the device clock: cg_strong_scaling_events times the
+    caller's launch shape, cg_laplace_time_events the tiled whole-grid stencil.  Both return mean
+    microseconds per launch: positive, growing with the grid, and never above the wall-clock figure of
+    strong_scaling for the same launch (which adds the launch and the synchronisation)."""
+    small = lib.strong_scaling_events(4096, 256, 1 << 20, 1024, 2, reps=10)
+    large = lib.strong_scaling_events(4 * 4096, 256, 1 << 22, 2048, 2, reps=10)
+    assert 0 < small < large < 1e6
+    wall = min(lib.strong_scaling(4 * 4096, 256, 1 << 22, 2048, 2) for _ in range(3))
+    assert large <= wall
+    # the reference's own shape, one thread per block, is far slower than 256 per block on the same grid
+    one = lib.strong_scaling_events(1 << 20, 1, 1 << 20, 1024, 2, reps=3)
+    assert one > 2 * small
+    t1 = lib.laplace_time_events(1024, 2, 0, reps=10)
+    t2 = lib.laplace_time_events(4096, 2, 0, reps=10)
+    assert 0 < t1 < t2 < 1e6
+    assert t2 < 4 * large             # four times the points of `large`, tiled: not slower per point
+    tm = lib.laplace_time_events(64, 3, 2, reps=10)      # Morton layout
+    assert 0 < tm < 1e6
+
+
 def test_reference_kernel_names_via_compat_launch(lib, oracle):
     """laplace_gpu_jl with a launch that does not cover the grid takes the reference-named
     one-point-per-thread kernel; index_mode 2 there is the Morton stencil."""
