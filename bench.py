@@ -62,8 +62,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal: host-staged)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every GPU owns a --workload grid; strong: the --workload grid is cut into --gpus slabs")
-    ap.add_argument("--comm", default="auto", help="multi-rank exchange: auto (direct xGMI boxes if they pass a "
-                    "self-check, else collectives) | links | collectives")
+    ap.add_argument("--comm", default="auto", help="multi-rank exchange: auto (the fastest of the library's RCCL calls, "
+                    "the direct xGMI boxes and the Python-driven collectives that passes a self-check) | rccl | links | collectives")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps iterations; the median is reported")
@@ -463,36 +463,60 @@ def main():
                 seen = [(dt, err)]
             return max(t for t, _ in seen), hist, "; ".join(e for _, e in seen if e)
 
-        if args.comm in ("auto", "links"):
-            # the direct path is used only if every rank mapped every box, the boxes reproduce the
-            # collectives' residual history and ghost planes bit for bit, and it is not slower
+        # Transport: the library's own RCCL calls (graph-captured), the direct xGMI boxes, or the Python-driven
+        # collectives.  A candidate is used only if it could be set up on every rank, reproduces the
+        # collectives' residual history, delivers ghost planes that equal the neighbours' boundary planes
+        # bit for bit, and (with --comm auto) was the fastest in a 30-iteration probe.
+        candidates = {"auto": ["rccl", "links"], "rccl": ["rccl"], "links": ["links"], "collectives": []}[args.comm]
+        if args.backend != "nccl" and world > 1:
+            candidates = [c for c in candidates if c != "rccl"]   # rehearsal backends share one GPU: RCCL refuses that
+        probes = {}
+        if candidates:
             t_coll, hist_c, err_c = probe()
             if err_c:
                 raise SystemExit(f"probe over the collectives failed: {err_c}")
-            if s.enable_links():
-                t_link, hist_l, err_l = probe()
-                ok = int(not err_l and len(hist_l) == 3 and
-                         all(abs(a - c) <= 1e-5 * abs(c) for a, c in zip(hist_l, hist_c)))
-                if not ok:
-                    comm_note = err_l or f"self-check mismatch {hist_l} vs {hist_c}"
+            probes["collectives"] = t_coll
+            notes = []
+            for name in candidates:
+                up = s.enable_rccl() if name == "rccl" else s.enable_links()
+                if not up:
+                    notes.append(f"{name}: {s.rccl_reason if name == 'rccl' else s.links_reason}")
+                    continue
+                t_new, hist_n, err_n = probe()
+                ok = int(not err_n and len(hist_n) == 3 and
+                         all(abs(a - c) <= 1e-5 * abs(c) for a, c in zip(hist_n, hist_c)))
+                why = "" if ok else (err_n or f"self-check mismatch {hist_n} vs {hist_c}")
                 mine = ok
                 ok = s._all_agree(ok)
                 if mine and not ok:
-                    comm_note = "self-check failed on another rank"
+                    why = "self-check failed on another rank"
                 if ok and not s._all_agree(s.ghosts_match_neighbours()):
-                    ok, comm_note = False, "self-check: ghost planes differ from the neighbours' boundary planes"
-                if ok and args.comm == "auto" and t_link > t_coll:
-                    ok, comm_note = False, f"boxes slower than collectives in the probe ({t_link:.4f} s vs {t_coll:.4f} s)"
+                    ok, why = False, "ghost planes differ from the neighbours' boundary planes"
                 if ok:
-                    comm = "xgmi-links"
-                    comm_note = f"probe: {t_link:.4f} s vs {t_coll:.4f} s over collectives for 30 iterations"
+                    probes[name] = t_new
+                else:
+                    notes.append(f"{name}: {why}")
+                if name == "rccl":
+                    s.disable_rccl()
                 else:
                     s.disable_links()
+            usable = [c for c in candidates if c in probes]
+            if args.comm == "auto":
+                pick = min(["collectives"] + usable, key=lambda c: probes[c])
+            elif usable:
+                pick = usable[0]
             else:
-                comm_note = s.links_reason
-            if args.comm == "links" and comm != "xgmi-links":
-                raise SystemExit(f"direct links unavailable: {comm_note}")
+                raise SystemExit(f"--comm {args.comm} unavailable: {'; '.join(notes)}")
+            if pick == "rccl" and not s.enable_rccl():
+                pick = "collectives"
+            if pick == "links" and not s.enable_links():
+                pick = "collectives"
+            comm = {"rccl": "rccl-in-library", "links": "xgmi-links", "collectives": "collectives"}[pick]
+            comm_note = "probe seconds for 30 iterations: " + ", ".join(f"{k} {v:.4f}" for k, v in probes.items())
+            if notes:
+                comm_note += "; " + "; ".join(notes)
             x.zero_()
+
         def timed():
             x.zero_()
             barrier()
@@ -516,16 +540,17 @@ def main():
         try:
             times, res = timed()
         except RuntimeError as e:
-            if comm != "xgmi-links":
+            if comm == "collectives":
                 raise
-            ok, comm_note = 0, "timed run over the boxes failed: " + str(e)
-        if comm == "xgmi-links" and not s._all_agree(ok):
-            # a rank lost the direct path under load: everyone goes back to the collectives
+            ok, comm_note = 0, f"timed run over {comm} failed: " + str(e)
+        if comm != "collectives" and not s._all_agree(ok):
+            # a rank lost the fast path under load: everyone goes back to the collectives
             s.disable_links()
+            s.disable_rccl()
             comm = "collectives"
             times, res = timed()
         parallelism = f"slab{world}"
-        if comm == "xgmi-links":
+        if comm != "collectives":
             with s._ctx():
                 msA, msB = s.ops.solver.time_kernels(max(10, min(50, args.steps)))
                 s.sync()

@@ -27,6 +27,7 @@ EXPORTS = [
     "cg_links_box_bytes", "cg_links_alloc", "cg_links_free", "cg_links_peer_ok", "cg_links_export", "cg_links_open",
     "cg_links_close", "cg_links_poke", "cg_links_peek", "cg_solver_bind_links", "cg_solver_exchange", "cg_solver_links_error",
     "cg_solver_links_times", "cg_noalloc_prepare", "cg_inner_product_noalloc",
+    "cg_solver_bind_partials_n", "cg_rccl_unique_id", "cg_rccl_comm_create", "cg_rccl_comm_destroy", "cg_solver_bind_rccl",
 ]
 
 
@@ -170,6 +171,16 @@ class Library:
         c.cg_solver_links_error.restype = i32
         c.cg_solver_links_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         c.cg_solver_links_times.restype = None
+        c.cg_solver_bind_partials_n.argtypes = [vp, vp, vp, i32]
+        c.cg_solver_bind_partials_n.restype = None
+        c.cg_rccl_unique_id.argtypes = [C.c_char_p]
+        c.cg_rccl_unique_id.restype = i32
+        c.cg_rccl_comm_create.argtypes = [C.c_char_p, i32, i32, C.POINTER(C.c_void_p)]
+        c.cg_rccl_comm_create.restype = i32
+        c.cg_rccl_comm_destroy.argtypes = [vp]
+        c.cg_rccl_comm_destroy.restype = i32
+        c.cg_solver_bind_rccl.argtypes = [vp, vp, i32, i32]
+        c.cg_solver_bind_rccl.restype = i32
         c.cg_noalloc_prepare.argtypes = []
         c.cg_noalloc_prepare.restype = i32
         c.cg_inner_product_noalloc.argtypes = [fp, fp, C.c_ulonglong, fp, vp]
@@ -305,6 +316,24 @@ class Library:
     def links_close(self, box):
         self.c.cg_links_close(_ptr(box))
 
+    # ---- RCCL communicator of the in-library multi-GPU path -------------------------------
+    def rccl_unique_id(self):
+        buf = C.create_string_buffer(128)
+        e = self.c.cg_rccl_unique_id(buf)
+        if e:
+            raise RuntimeError(f"cg_rccl_unique_id failed with ncclResult {e}")
+        return buf.raw
+
+    def rccl_comm_create(self, unique_id, rank, world):
+        comm = C.c_void_p()
+        e = self.c.cg_rccl_comm_create(C.create_string_buffer(bytes(unique_id), 128), rank, world, C.byref(comm))
+        if e or not comm.value:
+            raise RuntimeError(f"cg_rccl_comm_create failed with ncclResult {e}")
+        return comm.value
+
+    def rccl_comm_destroy(self, comm):
+        self.c.cg_rccl_comm_destroy(_ptr(comm))
+
     def make_solver(self, extents, index_mode=0, has_lo=0, has_hi=0, stream=None, r_buf=None, p0_buf=None,
                     p1_buf=None, engine=0):
         return Solver(self, extents, index_mode, has_lo, has_hi, stream, r_buf, p0_buf, p1_buf, engine)
@@ -391,8 +420,18 @@ class Solver:
     def bind_sums(self, pAp, rr):
         self.lib.c.cg_solver_bind_sums(self.h, _ptr(pAp), _ptr(rr))
 
-    def bind_partials(self, pAp_parts, rr_parts):
-        self.lib.c.cg_solver_bind_partials(self.h, _ptr(pAp_parts), _ptr(rr_parts))
+    def bind_partials(self, pAp_parts, rr_parts, n=None):
+        """n: number of addends every rank reduces (the largest `blocks` over the ranks)."""
+        if n is None:
+            self.lib.c.cg_solver_bind_partials(self.h, _ptr(pAp_parts), _ptr(rr_parts))
+        else:
+            self.lib.c.cg_solver_bind_partials_n(self.h, _ptr(pAp_parts), _ptr(rr_parts), n)
+
+    def bind_rccl(self, comm, rank, world):
+        """comm: an ncclComm_t address (Library.rccl_comm_create); None unbinds.  Collective."""
+        e = self.lib.c.cg_solver_bind_rccl(self.h, _ptr(comm), rank, world)
+        if e:
+            raise RuntimeError(f"cg_solver_bind_rccl failed with ncclResult {e}")
 
     def init_state(self, rel, lagged, maxit):
         self.lib.c.cg_solver_init_state(self.h, rel, lagged, maxit)

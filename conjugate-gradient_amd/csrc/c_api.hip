@@ -482,6 +482,8 @@ struct cg_solver
   explicit cg_solver(const SolverDesc &d) : impl(d) {}
 };
 
+Solver &cg_solver_impl(cg_solver *s) { return s->impl; }
+
 static SolverDesc to_desc(const cg_solver_desc *c)
 {
   CG_REQUIRE(c != nullptr, "null solver description");
@@ -535,6 +537,12 @@ extern "C" void cg_solver_bind_sums(cg_solver *s, const double *pAp, const doubl
 extern "C" void cg_solver_bind_partials(cg_solver *s, double *pAp_parts, double *rr_parts)
 {
   s->impl.bind_partials(pAp_parts, rr_parts);
+}
+extern "C" void cg_solver_bind_partials_n(cg_solver *s, double *pAp_parts, double *rr_parts, int n)
+{
+  CG_REQUIRE(n >= s->impl.blocks() && n <= 2 * CG_MAX_BLOCKS, "addend count must cover this solver's workgroups");
+  s->impl.bind_partials(pAp_parts, rr_parts);
+  s->impl.bind_sums(pAp_parts, n, rr_parts, n);
 }
 extern "C" void cg_solver_init_state(cg_solver *s, double rel, int lagged, int maxit)
 {

@@ -29,18 +29,22 @@ struct PlanesGeom
   unsigned nxc, nyt, nzs; // tiles along axis 0 (256 points), axis 1 (TY rows), segments of axis 2
   unsigned nitems;
   int has_lo, has_hi;
+  // marching direction along axis 2 of kernels A and B (+1: ascending, -1: descending).  Opposite
+  // directions let each kernel start where the other one stopped, on planes the Infinity Cache still holds.
+  int dir_a, dir_b;
 };
 
 constexpr int CG_PLANES_MAX_WAVES = 8;
 
-template <int MODE, bool GHOST, int POL, int R>
+template <int MODE, bool GHOST, int POL, int R, bool ASC = true>
 __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArgs a)
 {
   __shared__ double sh[8];
   // [plane parity][wave][0 = first row, 1 = last row][lane]
   __shared__ float4 halo[2][CG_PLANES_MAX_WAVES][2][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
-  constexpr bool NT = POL != POL_PLAIN;
+  constexpr bool NT = POL != POL_PLAIN; // x and all stores
+  constexpr bool NTS = NT;
   Src<MODE, POL> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
@@ -73,15 +77,18 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
   const long long sy = g.s0, sz = sy * n1;
   const bool tail = (g.n0 & 3u) != 0; // padded rows: see k_rows
   const unsigned TY = (unsigned)nw * R;
+  // planes are visited in order z = zs + dir * step; "behind" (pm) is z - dir, "ahead" (pn) is z + dir
+  constexpr long long dir = ASC ? 1 : -1;
+  constexpr bool asc = ASC;
 
   for (unsigned item = blockIdx.x; item < g.nitems; item += gridDim.x)
   {
-    const unsigned zs = item % g.nzs;
+    const unsigned zseg = item % g.nzs;
     unsigned t = item / g.nzs;
     const unsigned xc = t % g.nxc;
     const unsigned yt = t / g.nxc;
-    const long long z0 = (long long)((unsigned long long)zs * g.n2 / g.nzs);
-    const long long z1 = (long long)((unsigned long long)(zs + 1) * g.n2 / g.nzs);
+    const long long z0 = (long long)((unsigned long long)zseg * g.n2 / g.nzs);
+    const long long z1 = (long long)((unsigned long long)(zseg + 1) * g.n2 / g.nzs);
     if (z0 >= z1)
       continue;
     const unsigned x0 = xc * 256u + (unsigned)lane * 4u;
@@ -121,43 +128,51 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
     float4 pm[R], pc[R], pn[R];
     float ec[R], en[R];
     float4 hu_ext = zero4, hd_ext = zero4; // rows outside the tile, for the first / last wave
-    ldplane(z0 - 1, pm);
-    ldplane(z0, pc);
-    ldedges(z0, ec);
-    if (w == 0)
-      hu_ext = ldrow(yb - 1, z0);
-    if (w == nw - 1)
-      hd_ext = ldrow(yb + R, z0);
-    halo[z0 & 1][w][0][lane] = pc[0];
-    halo[z0 & 1][w][1][lane] = pc[R - 1];
-    if constexpr (MODE == MODE_A && GHOST)
-    {
-      if (g.has_lo && z0 == 0 && act)
+    const long long zs = asc ? z0 : z1 - 1, nz = z1 - z0;
+    // a plane just outside the slab that this rank must fill in p_new (a neighbouring rank owns it)
+    auto is_ghost = [&](long long z) { return (z == -1 && g.has_lo) || (z == n2 && g.has_hi); };
+    auto store_ghost = [&](long long z, const float4(&v)[R]) {
+      if constexpr (MODE == MODE_A && GHOST)
       {
+        if (is_ghost(z) && act)
+        {
 #pragma unroll
-        for (int j = 0; j < R; j++)
-          if (yb + j < n1)
-            store4<NT>(p_new + (-1) * sz + (yb + j) * sy + xcl, pm[j]);
+          for (int j = 0; j < R; j++)
+            if (yb + j < n1)
+              store4<NTS>(p_new + z * sz + (yb + j) * sy + xcl, v[j]);
+        }
       }
-    }
+    };
+    ldplane(zs - dir, pm);
+    ldplane(zs, pc);
+    ldedges(zs, ec);
+    if (w == 0)
+      hu_ext = ldrow(yb - 1, zs);
+    if (w == nw - 1)
+      hd_ext = ldrow(yb + R, zs);
+    halo[0][w][0][lane] = pc[0];
+    halo[0][w][1][lane] = pc[R - 1];
+    store_ghost(zs - dir, pm);
     __syncthreads();
 
-    for (long long z = z0; z < z1; z++)
+    for (long long step = 0; step < nz; step++)
     {
-      const bool more = z + 1 < z1;
+      const long long z = zs + dir * step;
+      const int par = (int)(step & 1);
+      const bool more = step + 1 < nz;
       // ---- loads for the next plane and this plane's x, r ---------------------------------
-      ldplane(z + 1, pn);
+      ldplane(z + dir, pn);
       float4 hu_n = zero4, hd_n = zero4;
 #pragma unroll
       for (int j = 0; j < R; j++)
         en[j] = 0.0f;
       if (more)
       {
-        ldedges(z + 1, en);
+        ldedges(z + dir, en);
         if (w == 0)
-          hu_n = ldrow(yb - 1, z + 1);
+          hu_n = ldrow(yb - 1, z + dir);
         if (w == nw - 1)
-          hd_n = ldrow(yb + R, z + 1);
+          hd_n = ldrow(yb + R, z + dir);
       }
       float4 xv[R], rv[R];
       if constexpr (MODE == MODE_B)
@@ -171,8 +186,8 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
         }
       }
       // ---- rows just outside this wave's rows, plane z ------------------------------------
-      const float4 hu = (w == 0) ? hu_ext : halo[z & 1][w - 1][1][lane];
-      const float4 hd = (w == nw - 1) ? hd_ext : halo[z & 1][w + 1][0][lane];
+      const float4 hu = (w == 0) ? hu_ext : halo[par][w - 1][1][lane];
+      const float4 hd = (w == nw - 1) ? hd_ext : halo[par][w + 1][0][lane];
 
 #pragma unroll
       for (int j = 0; j < R; j++)
@@ -182,6 +197,8 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
         const float4 c = pc[j];
         const float4 yu = (j + 1 < R) ? pc[(j + 1 < R) ? j + 1 : j] : hd; // y + 1
         const float4 yd = (j > 0) ? pc[(j > 0) ? j - 1 : j] : hu;         // y - 1
+        const float4 zu = asc ? pn[j] : pm[j];                            // z + 1
+        const float4 zd = asc ? pm[j] : pn[j];                            // z - 1
         float lft = __shfl_up(c.w, 1);
         float rgt = __shfl_down(c.x, 1);
         if (lane == 0)
@@ -197,10 +214,10 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
         lv.y += axis_term(yu.y, c.y, yd.y);
         lv.z += axis_term(yu.z, c.z, yd.z);
         lv.w += axis_term(yu.w, c.w, yd.w);
-        lv.x += axis_term(pn[j].x, c.x, pm[j].x);
-        lv.y += axis_term(pn[j].y, c.y, pm[j].y);
-        lv.z += axis_term(pn[j].z, c.z, pm[j].z);
-        lv.w += axis_term(pn[j].w, c.w, pm[j].w);
+        lv.x += axis_term(zu.x, c.x, zd.x);
+        lv.y += axis_term(zu.y, c.y, zd.y);
+        lv.z += axis_term(zu.z, c.z, zd.z);
+        lv.w += axis_term(zu.w, c.w, zd.w);
         if (!rowok)
           lv = zero4;
         if (tail)
@@ -221,7 +238,7 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
         else if constexpr (MODE == MODE_A)
         {
           if (rowok)
-            store4<NT>(p_new + idx, c);
+            store4<NTS>(p_new + idx, c);
           acc = fmaf(c.x, lv.x, acc);
           acc = fmaf(c.y, lv.y, acc);
           acc = fmaf(c.z, lv.z, acc);
@@ -241,7 +258,7 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
           if (rowok)
           {
             store4<NT>(a.x + idx, xo);
-            store4<NT>(a.r + idx, ro);
+            store4<NTS>(a.r + idx, ro);
           }
           else
             ro = zero4;
@@ -251,11 +268,11 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
           acc = fmaf(ro.w, ro.w, acc);
         }
       }
-      // ---- hand this wave's boundary rows of plane z+1 to its neighbours -------------------
+      // ---- hand this wave's boundary rows of the next plane to its neighbours ---------------
       if (more)
       {
-        halo[(z + 1) & 1][w][0][lane] = pn[0];
-        halo[(z + 1) & 1][w][1][lane] = pn[R - 1];
+        halo[par ^ 1][w][0][lane] = pn[0];
+        halo[par ^ 1][w][1][lane] = pn[R - 1];
       }
       __syncthreads();
 #pragma unroll
@@ -268,17 +285,8 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
       hu_ext = hu_n;
       hd_ext = hd_n;
     }
-    if constexpr (MODE == MODE_A && GHOST)
-    {
-      // pc now holds plane z1
-      if (g.has_hi && z1 == n2 && act)
-      {
-#pragma unroll
-        for (int j = 0; j < R; j++)
-          if (yb + j < n1)
-            store4<NT>(p_new + z1 * sz + (yb + j) * sy + xcl, pc[j]);
-      }
-    }
+    // pc now holds the plane just past the end of the march
+    store_ghost(zs + dir * nz, pc);
   }
   if constexpr (MODE != MODE_STENCIL)
     block_write_partial(acc, a.part_out, sh);

@@ -100,6 +100,15 @@ public:
   int links_error();                          // synchronises; 1 if a wait ever ran out of time
   void links_times(float *ms_xA, float *ms_xB) const; // exchange launches, from the last time_kernels
 
+  // ---- RCCL path: with a communicator bound, begin / iterate / finish run the multi-rank solve by
+  // themselves.  After kernel A one ncclAllReduce of the per-workgroup partials of p.Ap, after kernel B one of
+  // r.r and a grouped ncclSend / ncclRecv of r's boundary planes with the slab neighbours, all enqueued on
+  // stream() and captured in the same hipGraph as the kernels (no host work inside the loop).
+  // comm: an ncclComm_t whose rank r holds slab r (cg_rccl.hip creates one from a unique id); nullptr unbinds.
+  // Returns an ncclResult_t value, 0 = success.  Collective: every rank of the communicator calls it.
+  int bind_rccl(void *comm, int rank, int world);
+  bool rccl_bound() const { return rccl_; }
+
 private:
   void build_geometry();
   void launch_iteration(); // A, B and, with boxes bound, the exchange after each
@@ -144,6 +153,13 @@ private:
   SmallGeom smg_{};
   void launch_small();
   bool small_path() const;  // ... and nothing (slab neighbours, external sums, boxes) forbids it
+  bool rccl_ = false;
+  void *comm_ = nullptr;     // ncclComm_t
+  int comm_rank_ = 0, comm_world_ = 1;
+  int nparts_all_ = 0;       // the largest blocks() over the ranks: what every all-reduce carries
+  double *sum_bufs_ = nullptr; // [2][2 * CG_MAX_BLOCKS] all-reduced partials of p.Ap / r.r
+  void rccl_allreduce(int which);
+  void rccl_exchange_planes();
   bool linked_ = false;
   LinkArgs links_{};
   LinkCtl *link_ctl_ = nullptr;

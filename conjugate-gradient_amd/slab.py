@@ -9,10 +9,17 @@ iteration the ranks exchange
     (a few KiB of device doubles, no separate reduction launch); alpha and beta are then derived
     on every rank's device from identical bits, so all ranks take the same path.
 
-With `enable_links()` the ranks of one node drop the collectives and write the same data
-straight into each other's HBM over xGMI from a small kernel after A and after B (see
-csrc/cg_links.hpp); the whole multi-rank iteration is then four launches replayed from a
-hipGraph.  RCCL stays the portable default and the fallback.
+Three transports carry that traffic, the kernels are the same:
+
+  * `enable_rccl()` -- the library issues the RCCL calls itself (csrc/cg_rccl.hip: ncclAllReduce of the
+    partials, grouped ncclSend / ncclRecv of the planes) on the solver's stream, captured in the same
+    hipGraph as the kernels: no host work inside the loop.  The default on GPUs.
+  * `enable_links()` -- the ranks of one node write the same data straight into each other's HBM over
+    xGMI from a small kernel after A and after B (csrc/cg_links.hpp); four launches per iteration,
+    replayed from a hipGraph.
+  * neither -- this module drives the steps and calls torch.distributed between them (one
+    batch_isend_irecv and two all_reduce per iteration from Python): the portable fallback, and what
+    the gloo rehearsals on CPU tensors exercise.
 
 Everything is enqueued asynchronously on the current stream; the host never waits inside
 the loop.  The compute steps are the HIP library's kernels (binding.Solver); a different
@@ -52,6 +59,19 @@ class HipSlabOps:
                                       p1_buf=self.p1_buf.data_ptr())
         self.solver.bind_partials(self.parts[0].data_ptr(), self.parts[1].data_ptr())
         self.nparts = self.solver.blocks
+
+    def set_nparts(self, n):
+        """Ranks whose slabs differ in shape own different numbers of workgroups; all of them reduce
+        n = the largest count (the tail of a shorter array stays zero)."""
+        if n > self.parts.shape[1]:
+            raise ValueError(f"{n} partial sums exceed the {self.parts.shape[1]} slots")
+        self.nparts = int(n)
+        self.rebind_partials()
+
+    def rebind_partials(self):
+        self.parts.zero_()
+        torch.cuda.synchronize(self.device)
+        self.solver.bind_partials(self.parts[0].data_ptr(), self.parts[1].data_ptr(), self.nparts)
 
     def stream_ctx(self):
         return torch.cuda.stream(self.stream)
@@ -103,6 +123,9 @@ class SlabCG:
             raise ValueError("slab decomposition needs d >= 2")
         self.links = False
         self.links_reason = ""
+        self.rccl = False
+        self.rccl_reason = ""
+        self._comm = None
         self.has_lo = self.rank > 0
         self.has_hi = self.rank < self.world - 1
         self.N = 1
@@ -115,6 +138,13 @@ class SlabCG:
         else:
             self.ops = make_ops(self.extents, int(self.has_lo), int(self.has_hi))
         o = self.ops
+        # every rank all-reduces the same number of partial sums (slabs of different shape launch
+        # different numbers of workgroups)
+        if self.world > 1 and hasattr(o, "nparts"):
+            counts = [None] * self.world
+            dist.all_gather_object(counts, int(o.nparts), group=self.group)
+            if len(set(counts)) > 1:
+                o.set_nparts(max(counts))
         g, n, pl = o.ghost_offset, self.N, o.plane
         # views used by the halo exchange
         self.r_ghost_lo = o.r_buf[g - pl:g]
@@ -176,12 +206,69 @@ class SlabCG:
         for dst, buf in recvs:
             dst.copy_(buf)
 
+    # -- RCCL issued by the library ---------------------------------------------------------
+    def enable_rccl(self):
+        """Create an RCCL communicator over this group's ranks (unique id from rank 0, carried by
+        torch.distributed) and bind it to the solver.  Collective; True on all ranks or False on all."""
+        if self.rccl:
+            return True
+        if self.links:
+            self.disable_links()
+        lib, solver = self.ops.lib, self.ops.solver
+        ok, uid = 1, [None]
+        if self.rank == 0:
+            try:
+                uid = [lib.rccl_unique_id()]
+            except Exception as e:  # noqa: BLE001 -- any failure means "use another transport"
+                ok, self.rccl_reason = 0, repr(e)
+        src = self._global_rank(0)
+        dist.broadcast_object_list(uid, src=src, group=self.group)
+        if uid[0] is None:
+            ok = 0
+        if self._all_agree(ok):
+            try:
+                with self._ctx():
+                    self._comm = lib.rccl_comm_create(uid[0], self.rank, self.world)
+            except Exception as e:  # noqa: BLE001
+                ok, self.rccl_reason = 0, repr(e)
+        else:
+            ok = 0
+        if not self._all_agree(ok):
+            self._release_rccl()
+            return False
+        try:
+            solver.bind_rccl(self._comm, self.rank, self.world)
+        except Exception as e:  # noqa: BLE001
+            ok, self.rccl_reason = 0, repr(e)
+        if not self._all_agree(ok):
+            self._release_rccl()
+            return False
+        self.rccl = True
+        return True
+
+    def disable_rccl(self):
+        """Back to the Python-driven collectives (collective call)."""
+        if not self.rccl:
+            return
+        self.ops.solver.bind_rccl(None, 0, 1)       # waits for this rank's stream
+        self.ops.rebind_partials()
+        self.rccl = False
+        dist.barrier(group=self.group)
+        self._release_rccl()
+
+    def _release_rccl(self):
+        if self._comm:
+            self.ops.lib.rccl_comm_destroy(self._comm)
+            self._comm = None
+
     # -- direct xGMI path ---------------------------------------------------------------
     def enable_links(self):
         """Map every rank's box into this process and bind them to the solver.  Collective: all
         ranks call it; returns True on all ranks or False on all ranks (then nothing changed)."""
         if self.links:
             return True
+        if self.rccl:
+            self.disable_rccl()
         lib, solver = self.ops.lib, self.ops.solver
         ok, handle = 1, b""
         try:
@@ -247,7 +334,7 @@ class SlabCG:
         if not self.links:
             return
         self.ops.solver.bind_links(self.rank, [])   # waits for this rank's stream
-        self.ops.solver.bind_partials(self.ops.parts[0].data_ptr(), self.ops.parts[1].data_ptr())
+        self.ops.rebind_partials()
         self.links = False
         dist.barrier(group=self.group)                # nobody writes into a box any more
         self._release_links()
@@ -307,7 +394,7 @@ class SlabCG:
     def begin(self, b, x, rel=1e-6, lagged=1):
         """b, x: this rank's slab (N floats each).  r = b, p = 0, global r.r, ghost planes of r."""
         with self._ctx():
-            if self.links:
+            if self.links or self.rccl:
                 self.ops.begin_linked(b, x, rel, lagged)
                 return
             self.ops.begin_local(b, x)
@@ -317,7 +404,7 @@ class SlabCG:
 
     def iterate(self, n):
         with self._ctx():
-            if self.links:
+            if self.links or self.rccl:
                 self.ops.solver.iterate(n, True)
                 return
             self.ops.add_iterations(n)

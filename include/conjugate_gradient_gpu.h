@@ -215,6 +215,31 @@ extern "C"
   float *cg_solver_r(cg_solver *s);
   float *cg_solver_p(cg_solver *s, int which);
 
+  /* alternative to cg_solver_bind_partials for ranks whose solvers have different cg_solver_blocks():
+   * the kernels write their own cg_solver_blocks() partials but read n addends (n = the largest
+   * cg_solver_blocks() over the ranks, at most 4096), so that all ranks can all-reduce arrays of one
+   * length; the caller keeps the tail [cg_solver_blocks(), n) of its arrays zero before the reduction */
+  void cg_solver_bind_partials_n(cg_solver *s, double *pAp_parts, double *rr_parts, int n);
+
+  /* --- multi-GPU on RCCL (over xGMI inside a node): the halo exchange and the two dot-product
+   * all-reduces of the slab decomposition, issued by the library itself (no counterpart in the
+   * reference, which is single-GPU).  One rank per GPU, rank r owns slab r along the slowest axis
+   * (has_lo = r > 0, has_hi = r + 1 < world in its cg_solver_desc).  Rank 0 makes a unique id
+   * (cg_rccl_unique_id) and hands the 128 bytes to the other ranks over any channel; every rank, with
+   * its GPU current, creates its communicator (cg_rccl_comm_create, collective) -- or brings an
+   * ncclComm_t it already has -- and binds it (cg_solver_bind_rccl, collective).  From then on
+   * cg_solver_begin / cg_solver_iterate / cg_solver_finish run the multi-rank solve: per iteration
+   * kernel A, ncclAllReduce of the partials of p.Ap, kernel B, ncclAllReduce of the partials of r.r,
+   * grouped ncclSend / ncclRecv of r's boundary planes -- all on the solver's stream and replayed from
+   * one hipGraph, no host work inside the loop.  Every rank passes the same rel / lagged / iteration
+   * counts.  All four return an ncclResult_t value, 0 = success (a message goes to stderr otherwise);
+   * cg_solver_bind_rccl(s, NULL, 0, 1) unbinds. */
+#define CG_RCCL_ID_BYTES 128
+  int cg_rccl_unique_id(unsigned char *id128);
+  int cg_rccl_comm_create(const unsigned char *id128, int rank, int world, void **comm);
+  int cg_rccl_comm_destroy(void *comm);
+  int cg_solver_bind_rccl(cg_solver *s, void *comm, int rank, int world);
+
   /* --- direct xGMI path: slab neighbours write into each other's HBM, no collective library ---
    * (no counterpart in the reference, which is single-GPU).  Every rank allocates a box,
    * passes its handle to the other ranks of the node (any channel: the 64 bytes are plain

@@ -21,7 +21,11 @@ class FakeSlabOps:
         self.has_lo, self.has_hi = bool(has_lo), bool(has_hi)
         self.r_buf = torch.zeros(self.buffer_len, dtype=torch.float32)
         self.p_buf = [torch.zeros(self.buffer_len, dtype=torch.float32) for _ in range(2)]
-        self.dots = torch.zeros(2, dtype=torch.float64)
+        # like the HIP kernels, a slab hands over an array of partial sums whose length depends on its
+        # shape; the driver must make all ranks reduce arrays of one length
+        self.nparts_own = 1 + self.ext[-1] % 3
+        self.nparts = self.nparts_own
+        self.dots = torch.zeros(2, 8, dtype=torch.float64)
         self.part = [0.0, 0.0]
         self.x = None
         self.it = 0
@@ -72,12 +76,20 @@ class FakeSlabOps:
         rr = self.r_buf[g:g + n].numpy().astype(np.float64)
         self.part[1] = float(np.dot(rr, rr))
 
+    def set_nparts(self, n):
+        assert self.nparts_own <= n <= self.dots.shape[1]
+        self.nparts = int(n)
+
     def sum_tensor(self, which):
-        self.dots[which] = self.part[which]
-        return self.dots[which:which + 1]
+        self.dots[which].zero_()
+        self.dots[which, self.nparts_own - 1] = self.part[which]   # the last slot this slab owns
+        return self.dots[which, :self.nparts]
+
+    def _dot(self, which):
+        return self.dots[which, :self.nparts].sum().item()
 
     def init_state(self, rel, lagged, maxit):
-        rr = np.float32(self.dots[1].item())
+        rr = np.float32(self._dot(1))
         self.it, self.done, self.active, self.maxit, self.lagged = 0, False, False, maxit, bool(lagged)
         self.reltol = np.float32(rel * float(np.float32(np.sqrt(np.float64(rr)))))
         self.hist = [rr]
@@ -87,7 +99,7 @@ class FakeSlabOps:
 
     def kernel_A(self):
         k = self.it
-        rr = np.float32(self.dots[1].item())
+        rr = np.float32(self._dot(1))
         rr_prev = self.hist[k - 1] if k > 0 else None
         test = rr_prev if (self.lagged and k > 0) else rr
         residue = np.float32(np.sqrt(np.float64(test)))
@@ -114,7 +126,7 @@ class FakeSlabOps:
         if not self.active:
             return
         k = self.it
-        pAp = np.float32(self.dots[0].item())
+        pAp = np.float32(self._dot(0))
         alpha = np.float32(self.hist[k] / pAp)
         pg = self._ghosted(self.p_buf[(k & 1) ^ 1])
         ap = self._stencil(pg)

@@ -1,4 +1,5 @@
-"""Worker for the multi-process slab tests: python slab_worker.py <out.npz> <L> <d> <iters> [hip|links].
+"""Worker for the multi-process slab tests:
+python slab_worker.py <out.npz> <L> <d> <iters> [cpu|hip|links] [h0,h1,...: slab heights, default equal].
 Reads RANK / WORLD_SIZE / MASTER_* from the environment (gloo).  Without `hip` the per-slab
 compute is the CPU stand-in; with `hip` every rank runs the HIP kernels on cuda:0 (the ranks
 share the one GPU, the exchange is staged through host memory because RCCL refuses two
@@ -26,16 +27,22 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg = load_package()
     from conjugate_gradient_amd.slab import SlabCG
-    assert L % world == 0
-    h = L // world
+    if len(sys.argv) > 6:
+        heights = [int(v) for v in sys.argv[6].split(",")]
+        assert len(heights) == world and sum(heights) == L
+    else:
+        assert L % world == 0
+        heights = [L // world] * world
+    h = heights[rank]
     ext = [L] * (d - 1) + [h]
     N = L ** d
     rng = np.random.default_rng(123)
     xt = rng.random(N).astype(np.float32)            # same on every rank
     from oracle import oracle as orc
     b = orc.Oracle().laplace_f32(xt, d, L)
-    n_loc = N // world
-    b_loc = torch.from_numpy(b[rank * n_loc:(rank + 1) * n_loc].copy())
+    plane = N // L
+    n_loc, first = h * plane, sum(heights[:rank]) * plane
+    b_loc = torch.from_numpy(b[first:first + n_loc].copy())
     x_loc = torch.zeros(n_loc, dtype=torch.float32)
     if hip:
         dev = torch.device("cuda", 0)
@@ -52,10 +59,10 @@ def main():
     if hip:
         assert s.ghosts_match_neighbours()
     x_loc = x_loc.cpu()
-    gathered = [torch.zeros(n_loc, dtype=torch.float32) for _ in range(world)]
-    dist.all_gather(gathered, x_loc)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, x_loc.numpy())
     if rank == 0:
-        np.savez(out, x=torch.cat(gathered).numpy(), xt=xt, b=b, iters=n, res=res, hist=np.array(hist))
+        np.savez(out, x=np.concatenate(gathered), xt=xt, b=b, iters=n, res=res, hist=np.array(hist))
     dist.barrier()
     dist.destroy_process_group()
 
