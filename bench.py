@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="2d-8192", help="2d-8192 | 3d-1024x128 | 3d-512 | 3d-1024 | 4d-128-morton | LxLx..[:mode]")
+    ap.add_argument("--workload", default="2d-8192", help="2d-8192 | 3d-1024x128 | 3d-512 | 3d-1024 | 4d-128-morton | mixed-3d-512 | LxLx..[:mode]")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-slab", action="store_true", help="run the multi-rank driver even with one rank")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal: host-staged)")
@@ -234,6 +234,64 @@ def roofline_of(run, traffic=None, traffic_note=None, traffic_detail=None):
     return roof
 
 
+def lap64(t):
+    """A t in double with torch tensor operations (t shaped [L] * d), for residual checks."""
+    d = t.dim()
+    out = 2 * d * t.clone()
+    for ax in range(d):
+        n = t.shape[ax]
+        lo = [slice(None)] * d
+        hi = [slice(None)] * d
+        lo[ax], hi[ax] = slice(0, n - 1), slice(1, n)
+        out[tuple(lo)] -= t[tuple(hi)]
+        out[tuple(hi)] -= t[tuple(lo)]
+    return out
+
+
+def run_mixed(args, lib, device):
+    """Workload mixed-<d>d-<L> (config "mixed precision, 3-D 512^3"): the outer double CG of
+    conjugate-gradient_cpu.cu:334-392 (to 1e-8 |b|) with the float GPU CG as inner solve (to 1e-3),
+    b = A x_true in double, x0 = 0.  A timed region is one whole solve; value = inner float CG iterations
+    per second over the whole solve, outer fp64 work included."""
+    import torch
+    m = re.fullmatch(r"mixed-(\d+)d-(\d+)", args.workload)
+    if not m:
+        raise SystemExit("mixed workloads are named mixed-<d>d-<L>, e.g. mixed-3d-512")
+    d, L = int(m.group(1)), int(m.group(2))
+    N = L ** d
+    gen = torch.Generator(device=device).manual_seed(7)
+    xt = torch.rand([L] * d, dtype=torch.float64, device=device, generator=gen)
+    b = lap64(xt).reshape(-1).contiguous()
+    x = torch.zeros_like(b)
+    times, outer, inner = [], 0, []
+    for _ in range(max(1, args.warmup > 0) + max(1, min(args.repeats, 3))):
+        x.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outer, inner = lib.preconditioned_cg_gpu(b.data_ptr(), x.data_ptr(), L, d)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    times = times[1:] if len(times) > 1 else times          # the first solve warms up (graph capture, allocation)
+    dt = statistics.median(times)
+    res = float(((b - lap64(x.reshape([L] * d)).reshape(-1)).norm() / b.norm()).item())
+    err = float((x - xt.reshape(-1)).abs().max().item())
+    total = int(sum(inner))
+    out = {"metric": "cg_iterations_per_sec", "value": round(total / dt, 3),
+           "unit": "inner float CG iterations/s over the whole mixed-precision solve (outer fp64 work included)",
+           "n_gpus": 1, "steps": total, "warmup": 1, "ms_per_step": round(dt / max(total, 1) * 1e3, 5),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 inner / f64 outer",
+           "data": "synthetic",
+           "config": {"workload": args.workload, "local_extents": [L] * d, "points_per_gpu": N, "parallelism": "single",
+                      "rhs": "A x_true in fp64, x_true = torch.rand seed 7", "x0": 0, "outer_tolerance": 1e-8,
+                      "inner_tolerance": 1e-3},
+           "timing": {"regions": len(times), "statistic": "median", "seconds_per_solve": round(dt, 4),
+                      "seconds_all": [round(t, 4) for t in times]},
+           "outer_iterations": int(outer), "inner_iterations": [int(v) for v in inner],
+           "fp64_relative_residual": res, "max_abs_error": err}
+    out.update(iteration_rates(N, total / dt))
+    print(json.dumps(out), flush=True)
+
+
 def iteration_rates(N, its):
     """Whole-iteration byte rates of `its` iterations/s on N points, both prices."""
     eff = BYTES["iter"]["effective"] * N * its / 1e9
@@ -389,6 +447,11 @@ def main():
 
     pkg = load_package()
     lib = pkg.load_library()
+    if args.workload.startswith("mixed-"):
+        if world > 1:
+            raise SystemExit("the mixed-precision workload is a single-GPU configuration")
+        run_mixed(args, lib, device)
+        return
     ext, mode = workload_extents(args.workload)
     if args.scaling == "strong" and world > 1:
         if ext[-1] % world:

@@ -139,11 +139,17 @@ __global__ void __launch_bounds__(256) k_exchange(const LinkArgs L)
       return;
     if (tid == 0)
     {
+      sh_bad = 0;
       const long long t0 = wall_clock64();
       while (__hip_atomic_load(&ctl->go[kind], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq)
       {
         if (wall_clock64() - t0 > 2 * L.budget)
+        {
+          // the publishing workgroup never got that far: report it and leave the ghost planes alone
+          ctl->error = 1;
+          sh_bad = 1;
           break;
+        }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -152,6 +158,8 @@ __global__ void __launch_bounds__(256) k_exchange(const LinkArgs L)
     return;
   // ---- neighbours' planes: staging -> ghost planes of r ------------------------------------
   __syncthreads();
+  if (sh_bad)
+    return; // a wait ran out of time: the staged planes may be stale
   __threadfence_system();
   if (has_lo)
     grid_copy(L.ghost_lo, links_staging(L.box[L.rank], par, LINK_FROM_LO, L.plane_pad), L.plane);

@@ -1168,7 +1168,17 @@ void Solver::launch_exchange(int kind, bool force)
     // one workgroup per 64 KiB of plane, at most 64: enough to fill the two links it writes to
     const size_t want = (plane_ * sizeof(float) + 65535) / 65536;
     blocks = (int)std::max<size_t>(1, std::min<size_t>(want, 64));
-    blocks = std::max(1, std::min(env_int("CG_LINKS_BLOCKS", blocks), 256));
+    // every workgroup but the last one to arrive waits inside the kernel for that last one, so all of them
+    // must be resident at once: never more than one workgroup per CU
+    static int cus = 0;
+    if (!cus)
+    {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 64;
+      (void)hipGetLastError();
+    }
+    blocks = std::max(1, std::min(env_int("CG_LINKS_BLOCKS", blocks), std::min(256, cus)));
   }
   hipLaunchKernelGGL(k_exchange, dim3(blocks), dim3(256), 0, stream_, L);
   CHECK(hipGetLastError());

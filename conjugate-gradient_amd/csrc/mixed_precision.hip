@@ -1,8 +1,11 @@
 // mixed_precision.hip -- outer double-precision CG preconditioned by the float GPU CG
 // (the outer loop of conjugate-gradient_cpu.cu:334-392; readme.md:81 and tasks.md:7-8 name
-// the float GPU solver as the inner solve).  Vectors stay on the device; only the scalars
-// alpha, beta and the norms travel to the host, which runs the control flow in double
-// exactly as the reference does.
+// the float GPU solver as the inner solve).  All vectors stay on the device.  An outer iteration is
+// four fused fp64 kernels around the inner solve -- S: A p and the partial sums of p.Ap; U: alpha, the
+// updates of x and r, the float copy of r and the partial sums of r.r; Z: the partial sums of r.z on the
+// float z; P: beta and p = z + beta p -- with alpha and beta derived on the device from the partial
+// sums.  The host reads one double per outer iteration (|r|, for the reference's stop test) and runs
+// the control flow exactly as the reference does.
 #include <math.h>
 #include <stdio.h>
 
@@ -16,110 +19,142 @@
 namespace cgamd
 {
 
-// w = A u in double, lexicographic, zero Dirichlet boundary (conjugate-gradient_cpu.cu:97-113)
-__global__ void __launch_bounds__(256) k_laplace_f64(double *__restrict__ w, const double *__restrict__ u, int d,
-                                                     unsigned L, unsigned long long N)
+// Scalars of the outer loop, on the device: kernel U derives alpha from the partial sums kernel S left
+// behind and kernel P derives beta from those of kernel Z, so the host is not involved between them.
+// r.M^-1 r is double-buffered by the parity of the outer iteration (kernel P of iteration j reads [j & 1]
+// in every workgroup while one thread writes [(j + 1) & 1]).
+struct MixState
 {
-  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += step)
+  double rMinvr[2];
+  double alpha, beta, pAp;
+};
+
+// coordinates by 32-bit division (N < 2^31): the stencil of conjugate-gradient_cpu.cu:97-113 at point i
+__device__ __forceinline__ double laplace_at_f64(const double *__restrict__ u, unsigned i, int d, unsigned L)
+{
+  const double c = u[i];
+  double lv = 0;
+  unsigned rem = i, s = 1;
+  for (int k = 0; k < d; k++)
   {
-    const double c = u[i];
-    double lv = 0;
-    unsigned long long rem = i, s = 1;
-    for (int k = 0; k < d; k++)
-    {
-      const unsigned ck = (unsigned)(rem % L);
-      rem /= L;
-      const double up = (ck + 1 < L) ? u[i + s] : 0.0;
-      const double um = (ck > 0) ? u[i - s] : 0.0;
-      lv = lv + ((-up + 2 * c) - um);
-      s *= L;
-    }
-    w[i] = lv;
+    const unsigned ck = rem % L;
+    rem /= L;
+    const double up = (ck + 1 < L) ? u[i + s] : 0.0;
+    const double um = (ck > 0) ? u[i - s] : 0.0;
+    lv = lv + ((-up + 2 * c) - um);
+    s *= L;
   }
+  return lv;
 }
 
-__global__ void __launch_bounds__(256) k_dot_f64(const double *__restrict__ v, const double *__restrict__ w,
-                                                 unsigned long long n, double *__restrict__ part)
+__device__ __forceinline__ void block_partial_f64(double acc, double *__restrict__ part, double *sh)
 {
-  __shared__ double sh[8];
-  double acc = 0;
-  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
-    acc = fma(v[i], w[i], acc);
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0)
     sh[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0)
-    part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    part[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
-// x += a p ; r -= a w
-__global__ void __launch_bounds__(256) k_update_f64(double *__restrict__ x, double *__restrict__ r,
-                                                    const double *__restrict__ p, const double *__restrict__ w, double a,
-                                                    unsigned long long n)
+// kernel S: w = A u and the partial sums of u.w (Ap and p.Ap of conjugate-gradient_cpu.cu:363-365 in one pass)
+__global__ void __launch_bounds__(256) k_stencil_dot_f64(double *__restrict__ w, const double *__restrict__ u, int d,
+                                                         unsigned L, unsigned N, double *__restrict__ part)
 {
-  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+  __shared__ double sh[8];
+  double acc = 0;
+  const unsigned step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += step)
+  {
+    const double lv = laplace_at_f64(u, i, d, L);
+    w[i] = lv;
+    acc = fma(u[i], lv, acc);
+  }
+  block_partial_f64(acc, part, sh);
+}
+
+// kernel U: alpha = r.M^-1 r / p.Ap (:365); x += alpha p, r -= alpha w (:366-371); the partial sums of r.r for
+// the stop test (:374) and the float copy of r the inner solve starts from
+__global__ void __launch_bounds__(256) k_update_dot_f64(double *__restrict__ x, double *__restrict__ r,
+                                                        float *__restrict__ rf, const double *__restrict__ p,
+                                                        const double *__restrict__ w, unsigned N, MixState *st, int parity,
+                                                        const double *__restrict__ partS, int nS,
+                                                        double *__restrict__ part)
+{
+  __shared__ double sh[8];
+  const double pAp = block_read_sum(partS, nS, sh);
+  const double a = st->rMinvr[parity] / pAp;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    st->alpha = a;
+    st->pAp = pAp;
+  }
+  double acc = 0;
+  const unsigned step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += step)
   {
     x[i] = x[i] + a * p[i];
-    r[i] = r[i] - a * w[i];
+    const double rn = r[i] - a * w[i];
+    r[i] = rn;
+    rf[i] = (float)rn;
+    acc = fma(rn, rn, acc);
   }
+  block_partial_f64(acc, part, sh);
 }
 
-// p = z + beta p
-__global__ void __launch_bounds__(256) k_xpay_f64(double *__restrict__ p, const double *__restrict__ z, double beta,
-                                                  unsigned long long n)
+// kernel Z: partial sums of r.z with z = M^-1 r still in float (:377)
+__global__ void __launch_bounds__(256) k_dot_rz_f64(const double *__restrict__ r, const float *__restrict__ zf, unsigned N,
+                                                    double *__restrict__ part)
 {
-  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
-    p[i] = z[i] + beta * p[i];
+  __shared__ double sh[8];
+  double acc = 0;
+  const unsigned step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += step)
+    acc = fma(r[i], (double)zf[i], acc);
+  block_partial_f64(acc, part, sh);
 }
 
-// r = b - w
-__global__ void __launch_bounds__(256) k_sub_f64(double *__restrict__ r, const double *__restrict__ b,
-                                                 const double *__restrict__ w, unsigned long long n)
+// kernel P: beta = r.z / (previous r.z) (:378); p = z + beta p (:379-382).  first: p = z, r.z is only stored (:348,353)
+__global__ void __launch_bounds__(256) k_xpay_f64(double *__restrict__ p, const float *__restrict__ zf, unsigned N,
+                                                  MixState *st, int parity, int first, const double *__restrict__ partZ,
+                                                  int nZ)
 {
-  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
-    r[i] = b[i] - w[i];
-}
-
-__global__ void __launch_bounds__(256) k_narrow(float *__restrict__ dst, const double *__restrict__ src,
-                                                unsigned long long n)
-{
-  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
-    dst[i] = (float)src[i];
-}
-
-__global__ void __launch_bounds__(256) k_widen(double *__restrict__ dst, const float *__restrict__ src,
-                                               unsigned long long n)
-{
-  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
-    dst[i] = (double)src[i];
-}
-
-struct Mixed
-{
-  hipStream_t s;
-  unsigned long long N;
-  int grid;
-  double *part, *out;
-  double *host;
-
-  double dot(const double *v, const double *w)
+  __shared__ double sh[8];
+  const double rz = block_read_sum(partZ, nZ, sh);
+  const double beta = first ? 0.0 : rz / st->rMinvr[parity];
+  if (blockIdx.x == 0 && threadIdx.x == 0)
   {
-    hipLaunchKernelGGL(k_dot_f64, dim3(grid), dim3(256), 0, s, v, w, N, part);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, s, part, grid, out);
-    CHECK(hipGetLastError());
-    CHECK(hipMemcpyAsync(host, out, sizeof(double), hipMemcpyDeviceToHost, s));
-    CHECK(hipStreamSynchronize(s));
-    return *host;
+    st->rMinvr[first ? parity : parity ^ 1] = rz;
+    st->beta = beta;
   }
-};
+  const unsigned step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += step)
+    p[i] = first ? (double)zf[i] : (double)zf[i] + beta * p[i];
+}
+
+// r = b - w and its float copy (:340-344)
+__global__ void __launch_bounds__(256) k_residual_f64(double *__restrict__ r, float *__restrict__ rf,
+                                                      const double *__restrict__ b, const double *__restrict__ w, unsigned N)
+{
+  const unsigned step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += step)
+  {
+    const double v = b[i] - w[i];
+    r[i] = v;
+    rf[i] = (float)v;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dot_f64(const double *__restrict__ v, const double *__restrict__ w, unsigned N,
+                                                 double *__restrict__ part)
+{
+  __shared__ double sh[8];
+  double acc = 0;
+  const unsigned step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += step)
+    acc = fma(v[i], w[i], acc);
+  block_partial_f64(acc, part, sh);
+}
 
 } // namespace cgamd
 
@@ -153,13 +188,25 @@ extern "C" int preconditioned_cg_gpu(const double *b, double *x, int L, int d, i
   hipStream_t s = inner.stream();
   order_after_default_stream(s); // the caller's b and x may come from work on the default stream
 
-  Mixed m;
-  m.s = s;
-  m.N = N;
-  m.grid = (int)std::min<unsigned long long>((N + 255) / 256, 2048ull);
-  CHECK(hipMalloc((void **)&m.part, (m.grid + 1) * sizeof(double)));
-  m.out = m.part + m.grid;
-  CHECK(hipHostMalloc((void **)&m.host, sizeof(double)));
+  const int grid = (int)std::min<unsigned long long>((N + 255) / 256, 2048ull);
+  const unsigned n32 = (unsigned)N;
+  // partial sums of the four kinds of dot product, the reduced value and the loop's scalars
+  double *parts, *sum_dev, *sum_host;
+  MixState *st;
+  CHECK(hipMalloc((void **)&parts, ((size_t)4 * grid + 1) * sizeof(double)));
+  CHECK(hipMalloc((void **)&st, sizeof(MixState)));
+  CHECK(hipMemsetAsync(st, 0, sizeof(MixState), s));
+  CHECK(hipHostMalloc((void **)&sum_host, sizeof(double)));
+  double *partS = parts, *partU = parts + grid, *partZ = parts + 2 * grid, *partD = parts + 3 * grid;
+  sum_dev = parts + 4 * grid;
+  // one value back to the host: the only synchronisation of an outer iteration besides the inner solve
+  auto read_sum = [&](const double *part) -> double {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, s, part, grid, sum_dev);
+    CHECK(hipGetLastError());
+    CHECK(hipMemcpyAsync(sum_host, sum_dev, sizeof(double), hipMemcpyDeviceToHost, s));
+    CHECK(hipStreamSynchronize(s));
+    return *sum_host;
+  };
 
   const size_t bytes = N * sizeof(double);
   double *xd, *bd, *r, *p, *w;
@@ -184,13 +231,12 @@ extern "C" int preconditioned_cg_gpu(const double *b, double *x, int L, int d, i
   CHECK(hipMalloc((void **)&w, bytes));
   CHECK(hipMalloc((void **)&rf, N * sizeof(float)));
   CHECK(hipMalloc((void **)&zf, N * sizeof(float)));
-  const dim3 G(m.grid), B(256);
+  const dim3 G(grid), B(256);
 
   int ncalls = 0;
-  // z = M^-1 r: float CG from 0 until |r_inner| <= 1e-3 |r| on the fresh residual, no cap
-  // (conjugate-gradient_cpu.cu:274-324), result widened into `dst`
-  auto precondition = [&](const double *rhs, double *dst) {
-    hipLaunchKernelGGL(k_narrow, G, B, 0, s, rf, rhs, N);
+  // zf = M^-1 r: float CG from 0 on the float copy of r until |r_inner| <= 1e-3 |r| on the fresh residual, no
+  // cap (conjugate-gradient_cpu.cu:274-324)
+  auto precondition = [&]() {
     CHECK(hipMemsetAsync(zf, 0, N * sizeof(float), s));
     inner.begin(rf, zf, 1e-3, 0);
     inner.run(-1, true);
@@ -200,31 +246,30 @@ extern "C" int preconditioned_cg_gpu(const double *b, double *x, int L, int d, i
     if (inner_iters && ncalls < inner_len)
       inner_iters[ncalls] = it;
     ncalls++;
-    hipLaunchKernelGGL(k_widen, G, B, 0, s, dst, zf, N);
-    CHECK(hipGetLastError());
   };
 
-  hipLaunchKernelGGL(k_laplace_f64, G, B, 0, s, w, xd, d, (unsigned)L, N);
-  hipLaunchKernelGGL(k_sub_f64, G, B, 0, s, r, bd, w, N);
-  const double tol = 1e-8 * sqrt(m.dot(bd, bd));
-  precondition(r, p);
-  CHECK(hipMemcpyAsync(w, p, bytes, hipMemcpyDeviceToDevice, s));
-  double rMinvr = m.dot(r, w);
+  // r = b - A x (:340-344), tol = 1e-8 |b| (:345)
+  hipLaunchKernelGGL(k_stencil_dot_f64, G, B, 0, s, w, xd, d, (unsigned)L, n32, partS);
+  hipLaunchKernelGGL(k_residual_f64, G, B, 0, s, r, rf, bd, w, n32);
+  hipLaunchKernelGGL(k_dot_f64, G, B, 0, s, bd, bd, n32, partD);
+  const double tol = 1e-8 * sqrt(read_sum(partD));
+  // p = M^-1 r, r.M^-1 r (:348-353)
+  precondition();
+  hipLaunchKernelGGL(k_dot_rz_f64, G, B, 0, s, r, zf, n32, partZ);
+  hipLaunchKernelGGL(k_xpay_f64, G, B, 0, s, p, zf, n32, st, 0, 1, partZ, grid);
   int it = 0;
   const int maxitter = 1000;
   while (it < maxitter)
   {
+    const int parity = it & 1;
     it++;
-    hipLaunchKernelGGL(k_laplace_f64, G, B, 0, s, w, p, d, (unsigned)L, N);
-    const double alpha = rMinvr / m.dot(p, w);
-    hipLaunchKernelGGL(k_update_f64, G, B, 0, s, xd, r, p, w, alpha, N);
-    if (sqrt(m.dot(r, r)) < tol)
+    hipLaunchKernelGGL(k_stencil_dot_f64, G, B, 0, s, w, p, d, (unsigned)L, n32, partS);
+    hipLaunchKernelGGL(k_update_dot_f64, G, B, 0, s, xd, r, rf, p, w, n32, st, parity, partS, grid, partU);
+    if (sqrt(read_sum(partU)) < tol)
       break;
-    precondition(r, w);
-    const double rMinvr_new = m.dot(r, w);
-    const double beta = rMinvr_new / rMinvr;
-    hipLaunchKernelGGL(k_xpay_f64, G, B, 0, s, p, w, beta, N);
-    rMinvr = rMinvr_new;
+    precondition();
+    hipLaunchKernelGGL(k_dot_rz_f64, G, B, 0, s, r, zf, n32, partZ);
+    hipLaunchKernelGGL(k_xpay_f64, G, B, 0, s, p, zf, n32, st, parity, 0, partZ, grid);
   }
   CHECK(hipGetLastError());
   CHECK(hipStreamSynchronize(s));
@@ -244,7 +289,8 @@ extern "C" int preconditioned_cg_gpu(const double *b, double *x, int L, int d, i
   CHECK(hipFree(w));
   CHECK(hipFree(rf));
   CHECK(hipFree(zf));
-  CHECK(hipFree(m.part));
-  CHECK(hipHostFree(m.host));
+  CHECK(hipFree(parts));
+  CHECK(hipFree(st));
+  CHECK(hipHostFree(sum_host));
   return it;
 }

@@ -130,3 +130,33 @@ def test_morton_128_4_equals_lexicographic(lib, monkeypatch, relayout):
     assert np.allclose(hl, hm, rtol=1e-4)
     diff = (xm - xl[lex_of_morton]).norm().item()
     assert diff <= 1e-4 * xl.norm().item()
+
+
+def test_mixed_precision_at_its_configuration_size(lib):
+    """Config "mixed precision, 3-D 512^3" (conjugate-gradient_cpu.cu:334-392 with the float GPU CG as the
+    inner solve): b = A x_true in double, from x0 = 0 the outer loop must reach its 1e-8 |b| tolerance in a
+    handful of outer iterations (bounded here at 12), every inner solve must take some float iterations,
+    and the fp64 residual recomputed with torch must be below 1e-8 -- a level the float solver alone
+    cannot reach on this grid."""
+    L, d = 512, 3
+
+    def lap(t):
+        out = 2 * d * t.clone()
+        for ax in range(d):
+            lo = [slice(None)] * d
+            hi = [slice(None)] * d
+            lo[ax], hi[ax] = slice(0, L - 1), slice(1, L)
+            out[tuple(lo)] -= t[tuple(hi)]
+            out[tuple(hi)] -= t[tuple(lo)]
+        return out
+
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    xt = torch.rand([L] * d, dtype=torch.float64, device="cuda", generator=gen)
+    b = lap(xt).reshape(-1).contiguous()
+    x = torch.zeros_like(b)
+    outer, inner = lib.preconditioned_cg_gpu(b.data_ptr(), x.data_ptr(), L, d)
+    assert 1 <= outer <= 12, (outer, inner)
+    assert len(inner) == outer and all(v > 0 for v in inner), (outer, inner)
+    res = ((b - lap(x.reshape([L] * d)).reshape(-1)).norm() / b.norm()).item()
+    assert res < 1e-8, res
+    assert (x - xt.reshape(-1)).abs().max().item() < 1e-5
