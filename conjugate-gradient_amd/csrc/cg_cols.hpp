@@ -72,6 +72,9 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
   }
   const float alpha = coef;
   float acc = 0;
+  float *push_lo = nullptr, *push_hi = nullptr;
+  if constexpr (MODE == MODE_B && GHOST)
+    push_targets(a, push_lo, push_hi);
   const float4 zero4 = make_float4(0, 0, 0, 0);
   constexpr int NA = D - 3; // column axes other than the blocked one
   const long long rs = (long long)g.sy; // between consecutive rows of the march (the last axis)
@@ -347,6 +350,14 @@ __global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
           {
             store4<STREAM>(a.x + ij, xo);
             store4<STREAM>(a.r + ij, ro);
+            if constexpr (GHOST)
+            {
+              // boundary hyperplanes of the slab (the march runs along the slab axis)
+              if (push_lo && y == 0)
+                store4<false>(push_lo + base + j * sb, ro);
+              if (push_hi && y + 1 == n1)
+                store4<false>(push_hi + base + j * sb, ro);
+            }
           }
           else
             ro = zero4;

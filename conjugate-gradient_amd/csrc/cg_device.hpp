@@ -90,7 +90,27 @@ struct VecArgs
   const double *sumB; // r.r as nB addends
   int nB;
   double *part_out; // this launch's per-block partials
+  // Direct xGMI path, kernel B only: r's first / last owned hyperplane also goes straight into the staging
+  // area of the rank below / above (null: nothing to push), so that the exchange launch after B only has to
+  // publish stamps and collect.  push_seq: exchanges of this kind completed so far (device memory); its
+  // parity selects the staging buffer, push_stride floats apart.
+  float *push_lo, *push_hi;
+  const unsigned long long *push_seq;
+  unsigned long long push_stride;
 };
+
+// staging buffers of this launch: the exchange that follows kernel B is number *push_seq + 1
+__device__ __forceinline__ void push_targets(const VecArgs &a, float *&lo, float *&hi)
+{
+  lo = nullptr;
+  hi = nullptr;
+  if (a.push_seq)
+  {
+    const unsigned long long par = (a.push_seq[0] + 1ull) & 1ull;
+    lo = a.push_lo ? a.push_lo + par * a.push_stride : nullptr;
+    hi = a.push_hi ? a.push_hi + par * a.push_stride : nullptr;
+  }
+}
 
 struct RowsGeom
 {
@@ -396,6 +416,9 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
   }
   const float alpha = coef;
   float acc = 0;
+  float *push_lo = nullptr, *push_hi = nullptr;
+  if constexpr (MODE == MODE_B && GHOST)
+    push_targets(a, push_lo, push_hi);
   const float4 zero4 = make_float4(0, 0, 0, 0);
   const int d = D > 0 ? D : g.d;
   // distance between consecutive rows of a march: packed columns march along the LAST axis
@@ -626,6 +649,25 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
         {
           store4<NT>(a.x + idx, xv);
           store4<NT>(a.r + idx, rv);
+          if constexpr (GHOST)
+          {
+            // boundary hyperplanes of the slab: also into the neighbours' staging areas
+            if (rowghost)
+            {
+              if (push_lo && y == 0)
+                store4<false>(push_lo + col0, rv);
+              if (push_hi && y + 1 == n1)
+                store4<false>(push_hi + col0, rv);
+            }
+            else if (d >= 3)
+            {
+              const long long s = (long long)g.sk[d - 3];
+              if (push_lo && st_lo)
+                store4<false>(push_lo + idx, rv);
+              if (push_hi && st_hi)
+                store4<false>(push_hi + (idx - (long long)(g.nk[d - 3] - 1u) * s), rv);
+            }
+          }
         }
         else
           rv = zero4;
@@ -686,11 +728,15 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
   }
   const float alpha = coef;
   float acc = 0;
+  float *push_lo = nullptr, *push_hi = nullptr;
+  if constexpr (MODE == MODE_B && GHOST)
+    push_targets(a, push_lo, push_hi);
   const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < g.N; i += step)
   {
     const float c = src.ld1((long long)i);
     float lv = 0.0f;
+    long long off_lo = -1, off_hi = -1; // position inside the first / last owned hyperplane
     if constexpr (LAYOUT == LAYOUT_LEX)
     {
       // N < 2^32, so 32-bit division.  (Replacing it by shifts or a multiply-high made the
@@ -714,6 +760,13 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
             p_new[(long long)i - s] = um;
           if (last && g.has_hi && ck + 1 == nk)
             p_new[(long long)i + s] = up;
+        }
+        if constexpr (MODE == MODE_B && GHOST)
+        {
+          if (last && ck == 0)
+            off_lo = (long long)i;
+          if (last && ck + 1 == nk)
+            off_hi = (long long)i - (long long)ck * s;
         }
       }
     }
@@ -746,6 +799,13 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
       const float rv = fmaf(-alpha, lv, a.r[i]);
       a.x[i] = xv;
       a.r[i] = rv;
+      if constexpr (GHOST)
+      {
+        if (push_lo && off_lo >= 0)
+          push_lo[off_lo] = rv;
+        if (push_hi && off_hi >= 0)
+          push_hi[off_hi] = rv;
+      }
       acc = fmaf(rv, rv, acc);
     }
   }

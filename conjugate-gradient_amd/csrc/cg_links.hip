@@ -55,7 +55,9 @@ __global__ void __launch_bounds__(256) k_exchange(const LinkArgs L)
   const bool has_lo = L.rank > 0, has_hi = L.rank + 1 < L.world;
 
   // ---- push this rank's boundary planes of r into the neighbours' staging areas ------------
-  if (planes)
+  // (not after an iteration's kernel B, which has stored them there itself while it ran: the end of that
+  // launch has made them visible before this one starts)
+  if (planes && !L.pushed)
   {
     if (has_lo)
       grid_copy(links_staging(L.box[L.rank - 1], par, LINK_FROM_HI, L.plane_pad), L.r_first, L.plane);

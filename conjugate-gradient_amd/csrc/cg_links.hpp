@@ -78,6 +78,7 @@ struct LinkArgs
   int rank, world;
   int kind;
   int force;          // run even if the state says the iteration is inactive (start of a solve)
+  int pushed;         // kernel B has already stored the boundary planes into the neighbours' staging areas
   const float *r_first, *r_last; // owned boundary planes (kind 1 with neighbours), else null
   float *ghost_lo, *ghost_hi;
   unsigned long long plane, plane_pad; // floats
@@ -90,7 +91,7 @@ __host__ __device__ inline size_t links_box_bytes(size_t plane)
 {
   return CG_LINKS_HEADER + 4 * links_plane_pad(plane) * sizeof(float);
 }
-__device__ __forceinline__ float *links_staging(LinkBox *box, int parity, int side, unsigned long long plane_pad)
+__host__ __device__ __forceinline__ float *links_staging(LinkBox *box, int parity, int side, unsigned long long plane_pad)
 {
   return reinterpret_cast<float *>(reinterpret_cast<char *>(box) + CG_LINKS_HEADER) +
          ((size_t)parity * 2 + side) * plane_pad;

@@ -72,6 +72,9 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
   }
   const float alpha = coef;
   float acc = 0;
+  float *push_lo = nullptr, *push_hi = nullptr;
+  if constexpr (MODE == MODE_B && GHOST)
+    push_targets(a, push_lo, push_hi);
   const float4 zero4 = make_float4(0, 0, 0, 0);
   const long long n1 = g.n1, n2 = g.n2;
   const long long sy = g.s0, sz = sy * n1;
@@ -259,6 +262,14 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
           {
             store4<NT>(a.x + idx, xo);
             store4<NTS>(a.r + idx, ro);
+            if constexpr (GHOST)
+            {
+              // boundary planes of the slab: also into the neighbours' staging areas
+              if (push_lo && z == 0)
+                store4<false>(push_lo + (yb + j) * sy + xcl, ro);
+              if (push_hi && z + 1 == n2)
+                store4<false>(push_hi + (yb + j) * sy + xcl, ro);
+            }
           }
           else
             ro = zero4;

@@ -886,6 +886,17 @@ void Solver::launch_B()
 {
   VecArgs a = args();
   a.part_out = partB_;
+  if (linked_ && push_in_b_ && (desc_.has_lo || desc_.has_hi))
+  {
+    // r's boundary planes travel while kernel B still runs: it stores them into the neighbours' staging
+    // areas as it produces them (parity 0 here; the kernel adds the parity of the coming exchange)
+    a.push_seq = &link_ctl_->seq[1];
+    a.push_stride = 2ull * links_.plane_pad;
+    if (desc_.has_lo)
+      a.push_lo = links_staging(links_.box[links_.rank - 1], 0, LINK_FROM_HI, links_.plane_pad);
+    if (desc_.has_hi)
+      a.push_hi = links_staging(links_.box[links_.rank + 1], 0, LINK_FROM_LO, links_.plane_pad);
+  }
   launch_mode(MODE_B, true, a);
 }
 
@@ -1147,6 +1158,7 @@ void Solver::bind_links(int rank, int world, void *const *boxes)
   partA_ = partA_own_;
   partB_ = partB_own_;
   bind_sums(&link_ctl_->sum[0], 1, &link_ctl_->sum[1], 1);
+  push_in_b_ = env_int("CG_LINKS_PUSH_IN_B", 1) != 0;
   linked_ = true;
 }
 
@@ -1156,6 +1168,7 @@ void Solver::launch_exchange(int kind, bool force)
   LinkArgs L = links_;
   L.kind = kind;
   L.force = force ? 1 : 0;
+  L.pushed = (!force && push_in_b_) ? 1 : 0;
   L.part = kind ? partB_ : partA_;
   L.nparts = grid_;
   int blocks = 1;

@@ -161,6 +161,7 @@ private:
   void rccl_allreduce(int which);
   void rccl_exchange_planes();
   bool linked_ = false;
+  bool push_in_b_ = true;    // kernel B stores r's boundary planes into the neighbours' staging areas itself
   LinkArgs links_{};
   LinkCtl *link_ctl_ = nullptr;
   float ms_xA_ = 0, ms_xB_ = 0;
