@@ -37,8 +37,11 @@ namespace cgamd
 // Exact rows (g.xl, both kernels through LDS): a row whose n0/4 lanes are not a power of two would idle up
 // to half of its slot; instead it takes exactly n0/4 lanes, rows cross wave boundaries, and the x
 // neighbours of a lane come from LDS as well instead of from lane shifts.
+#ifndef COLS_A_WAVES
+#define COLS_A_WAVES 0
+#endif
 template <int MODE, bool GHOST, int D, int R, bool STREAM, bool LDS>
-__global__ void __launch_bounds__(512) k_cols(const RowsGeom g, const VecArgs a)
+__global__ void __launch_bounds__(512, (MODE == MODE_A && COLS_A_WAVES) ? COLS_A_WAVES : 1) k_cols(const RowsGeom g, const VecArgs a)
 {
   __shared__ float4 hand[LDS ? 2 * R * 512 : 1];
   static_assert(D == 3 || D == 4 || D == 5, "columns in blocks: d = 3, 4 and 5");
