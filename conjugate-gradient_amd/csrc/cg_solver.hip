@@ -125,7 +125,7 @@ static int max_blocks()
 
 // Number of workgroups the chip keeps resident at once for the rows kernels: CUs times
 // workgroups per CU (kernel B needs 82 VGPRs: 5 workgroups of 256 fit; 4 measured fastest).  A grid of exactly this size runs as one round with no partial second round.
-static int resident_blocks()
+static int resident_blocks(int per_cu_override = 0)
 {
   static int cus = 0;
   if (!cus)
@@ -138,7 +138,7 @@ static int resident_blocks()
       cus = 256;
     (void)hipGetLastError();
   }
-  const int per_cu = std::max(1, env_int("CG_BLOCKS_PER_CU", 4));
+  const int per_cu = per_cu_override > 0 ? per_cu_override : std::max(1, env_int("CG_BLOCKS_PER_CU", 4));
   return std::min(cus * per_cu, max_blocks());
 }
 
@@ -183,7 +183,7 @@ static unsigned long long choose_segments(unsigned long long ncols, unsigned lon
 
 // columns x segments decomposition of the rows engine (see cg_device.hpp)
 static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, RowsGeom &g, int &block, int &grid,
-                           unsigned s0 = 0)
+                           unsigned s0 = 0, int per_cu = 0)
 {
   memset(&g, 0, sizeof(g));
   g.d = d;
@@ -288,8 +288,8 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
     }
   }
   // scale the resident-workgroup target by the workgroup size (it is counted in 256-thread units)
-  const unsigned long long target =
-      block > 256 ? (unsigned long long)resident_blocks() * 256 / block : (unsigned long long)resident_blocks() * (256 / block);
+  const unsigned long long target = block > 256 ? (unsigned long long)resident_blocks(per_cu) * 256 / block
+                                                : (unsigned long long)resident_blocks(per_cu) * (256 / block);
   unsigned long long bpc = choose_segments(ncols, target, g.n1, 4, 2.5); // at least ~4 rows per segment
   bpc = (unsigned long long)env_int("CG_ROWS_BPC", (int)bpc);
   bpc = std::max<unsigned long long>(1, std::min<unsigned long long>(bpc, g.n1));
@@ -304,7 +304,7 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
 
 // tiles x segments decomposition of the planes engine (see cg_planes.hpp)
 static void make_planes_geom(const unsigned *n, int has_lo, int has_hi, PlanesGeom &g, int &block, int &grid, int &R,
-                             unsigned s0 = 0)
+                             unsigned s0 = 0, int per_cu = 0)
 {
   memset(&g, 0, sizeof(g));
   g.n0 = n[0];
@@ -325,8 +325,8 @@ static void make_planes_geom(const unsigned *n, int has_lo, int has_hi, PlanesGe
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
     cus = prop.multiProcessorCount;
   (void)hipGetLastError();
-  const unsigned long long target =
-      std::min<unsigned long long>((unsigned long long)cus * std::max(1, env_int("CG_PLANES_BPCU", 2)), max_blocks());
+  const unsigned long long target = std::min<unsigned long long>(
+      (unsigned long long)cus * (per_cu > 0 ? per_cu : std::max(1, env_int("CG_PLANES_BPCU", 2))), max_blocks());
   // keep segments >= 8 planes; a segment costs more here than in the rows engine (three planes to start,
   // the LDS hand-off): 640^3 loses 8 % in kernel A with 17 segments instead of 4, 768^3 gains 4 % with 7
   // instead of 3
@@ -365,6 +365,28 @@ static void make_morton_geom(int d, unsigned long long N, MortonGeom &g, int &bl
   // with at least one LDS tile per workgroup the tiled kernel is used: never more workgroups than tiles
   if (N % CG_MORTON_TILE == 0 && N / CG_MORTON_TILE >= 64)
     grid = (int)std::min<unsigned long long>((unsigned long long)grid, N / CG_MORTON_TILE);
+  // large grids: columns of tiles along the last axis, three tiles in LDS (k_morton_march); one workgroup
+  // per CU (96 KiB of LDS each)
+  if (env_int("CG_MORTON_MARCH", 0) && N % CG_MARCH_TILE == 0 && N < (1ull << 32))
+  {
+    const unsigned ntiles = (unsigned)(N >> CG_MARCH_TILE_BITS);
+    const unsigned mm = ntiles ? (g.mmask[d - 1] >> CG_MARCH_TILE_BITS) & (ntiles - 1u) : 0u;
+    const unsigned len = 1u << __builtin_popcount(mm);
+    if (ntiles >= 512 && len >= 4 && ntiles / len >= 64)
+    {
+      int dev = 0, cus = 256;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        cus = prop.multiProcessorCount;
+      (void)hipGetLastError();
+      g.march_mask = mm;
+      g.march_len = len;
+      const unsigned ncols = ntiles / len;
+      const unsigned want = (unsigned)std::max(8, cus * std::max(1, env_int("CG_MORTON_MARCH_BPCU", 1)) / 8 * 8);
+      grid = (int)std::min(want, ncols / 8 * 8);
+      block = CG_MARCH_BT;
+    }
+  }
 }
 
 size_t Solver::plane_of(const SolverDesc &d)
@@ -633,24 +655,51 @@ void Solver::build_geometry()
   if (engine_ == ENGINE_PLANES)
     CG_REQUIRE(planes_ok, "the planes engine needs a 3-D lexicographic grid with n0 % 4 == 0");
 
+  // Kernel A and kernel B may be cut into work items differently (the number of resident workgroups each
+  // runs best with differs); gridB_ also launches the plain stencil and the dot product of begin_local().
+  // grid_ = the larger of the two is the number of partial-sum addends: the tail a kernel does not write
+  // stays zero.
   if (engine_ == ENGINE_ROWS)
   {
-    make_rows_geom(d, n, desc_.has_lo, desc_.has_hi, rg_, block_, grid_, s0_);
+    make_rows_geom(d, n, desc_.has_lo, desc_.has_hi, rg_, block_, gridB_, s0_);
+    // 2-D grids whose vectors exceed the Infinity Cache: kernel A (two reads per write, to a third array)
+    // streams best with 2 workgroups per CU, kernel B with 4 (16384 x 8192: A 356 -> 326 us with 2, B 486 ->
+    // 506).  Not the folded 1-D march (2^27 points: A 375 -> 448) and not grids the cache helps (8192^2: A
+    // 133 -> 159).
+    // (rows of at least 16384 points: 32768 x 4096 341 -> 320, 16384^2 653 -> 606; 8192 x 16384 loses, 365 -> 388)
+    const bool beyond = d == 2 && N_ >= (1ull << 27) && n[0] >= 16384u;
+    const int per_cu_a = env_int("CG_BLOCKS_PER_CU_A", beyond ? 2 : 0);
+    rgA_ = rg_;
+    blockA_ = block_;
+    gridA_ = gridB_;
+    if (per_cu_a > 0)
+      make_rows_geom(d, n, desc_.has_lo, desc_.has_hi, rgA_, blockA_, gridA_, s0_, per_cu_a);
   }
   else if (engine_ == ENGINE_PLANES)
   {
-    make_planes_geom(n, desc_.has_lo, desc_.has_hi, pg_, block_, grid_, planes_r_, s0_);
+    const int per_cu_b = env_int("CG_PLANES_BPCU_B", 0);
+    make_planes_geom(n, desc_.has_lo, desc_.has_hi, pg_, block_, gridB_, planes_r_, s0_, per_cu_b);
+    pgA_ = pg_;
+    blockA_ = block_;
+    gridA_ = gridB_;
+    if (per_cu_b > 0)
+      make_planes_geom(n, desc_.has_lo, desc_.has_hi, pgA_, blockA_, gridA_, planes_r_, s0_);
   }
   else if (engine_ == ENGINE_MORTON4)
   {
-    make_morton_geom(d, N_, mg_, block_, grid_);
+    make_morton_geom(d, N_, mg_, block_, gridB_);
+    gridA_ = gridB_;
+    blockA_ = block_;
   }
   else
   {
     block_ = 256;
     const unsigned long long nb = (N_ + block_ - 1) / block_;
-    grid_ = (int)std::min<unsigned long long>(nb, (unsigned long long)max_blocks());
+    gridB_ = (int)std::min<unsigned long long>(nb, (unsigned long long)max_blocks());
+    gridA_ = gridB_;
+    blockA_ = block_;
   }
+  grid_ = std::max(gridA_, gridB_);
 }
 
 const char *Solver::kernel_name() const
@@ -662,7 +711,9 @@ const char *Solver::kernel_name() const
   case ENGINE_ROWS: return rg_.R ? "k_cols" : "k_rows";
   case ENGINE_PLANES: return "k_planes";
   case ENGINE_MORTON4: // the same rule as launch_morton4
-    return (mg_.N >= (unsigned long long)CG_MORTON_TILE * grid_ && mg_.N % CG_MORTON_TILE == 0 && env_int("CG_MORTON_TILED", 1))
+    if (mg_.march_len)
+      return "k_morton_march";
+    return (mg_.N >= (unsigned long long)CG_MORTON_TILE * gridB_ && mg_.N % CG_MORTON_TILE == 0 && env_int("CG_MORTON_TILED", 1))
                ? "k_morton_tile"
                : "k_morton4";
   default: return "k_scalar";
@@ -782,9 +833,30 @@ static void launch_planes(const PlanesGeom &g, const VecArgs &a, int grid, int b
     launch_planes_pol<MODE, GHOST, POL_PLAIN>(g, a, grid, block, R, s);
 }
 
+template <int MODE, int POL>
+static void launch_morton_march(const MortonGeom &g, const VecArgs &a, int grid, hipStream_t s)
+{
+  static bool sized = false; // per instantiation: the kernel may use more than the default 64 KiB of LDS
+  if (!sized)
+  {
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_morton_march<MODE, POL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_MARCH_LDS_BYTES));
+    sized = true;
+  }
+  hipLaunchKernelGGL((k_morton_march<MODE, POL>), dim3(grid), dim3(CG_MARCH_BT), CG_MARCH_LDS_BYTES, s, g, a);
+}
+
 template <int MODE>
 static void launch_morton4(const MortonGeom &g, const VecArgs &a, int grid, int block, hipStream_t s, int pol = POL_PLAIN)
 {
+  if (g.march_len)
+  {
+    if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
+      launch_morton_march<MODE, POL_KEEP_R>(g, a, grid, s);
+    else
+      launch_morton_march<MODE, POL_PLAIN>(g, a, grid, s);
+    return;
+  }
   // grids of at least one tile per workgroup use the LDS-tiled kernel
   const bool tiled = g.N >= (unsigned long long)CG_MORTON_TILE * grid && g.N % CG_MORTON_TILE == 0 &&
                      env_int("CG_MORTON_TILED", 1);
@@ -816,35 +888,35 @@ void Solver::launch_mode(int mode, bool ghost, const VecArgs &a)
   {
     switch (mode)
     {
-    case MODE_A: launch_morton4<MODE_A>(mg_, a, grid_, block_, stream_, policy_); break;
-    case MODE_B: launch_morton4<MODE_B>(mg_, a, grid_, block_, stream_, policy_); break;
-    default: launch_morton4<MODE_STENCIL>(mg_, a, grid_, block_, stream_);
+    case MODE_A: launch_morton4<MODE_A>(mg_, a, gridA_, blockA_, stream_, policy_); break;
+    case MODE_B: launch_morton4<MODE_B>(mg_, a, gridB_, block_, stream_, policy_); break;
+    default: launch_morton4<MODE_STENCIL>(mg_, a, gridB_, block_, stream_);
     }
   }
   else if (engine_ == ENGINE_PLANES)
   {
     switch (mode)
     {
-    case MODE_A: launch_planes<MODE_A, true>(pg_, a, grid_, block_, planes_r_, stream_, policy_); break;
-    case MODE_B: launch_planes<MODE_B, true>(pg_, a, grid_, block_, planes_r_, stream_, policy_); break;
+    case MODE_A: launch_planes<MODE_A, true>(pgA_, a, gridA_, blockA_, planes_r_, stream_, policy_); break;
+    case MODE_B: launch_planes<MODE_B, true>(pg_, a, gridB_, block_, planes_r_, stream_, policy_); break;
     default:
       if (ghost)
-        launch_planes<MODE_STENCIL, true>(pg_, a, grid_, block_, planes_r_, stream_);
+        launch_planes<MODE_STENCIL, true>(pg_, a, gridB_, block_, planes_r_, stream_);
       else
-        launch_planes<MODE_STENCIL, false>(pg_, a, grid_, block_, planes_r_, stream_);
+        launch_planes<MODE_STENCIL, false>(pg_, a, gridB_, block_, planes_r_, stream_);
     }
   }
   else if (engine_ == ENGINE_ROWS)
   {
     switch (mode)
     {
-    case MODE_A: launch_rows<MODE_A, true>(rg_, a, grid_, block_, stream_, policy_); break;
-    case MODE_B: launch_rows<MODE_B, true>(rg_, a, grid_, block_, stream_, policy_); break;
+    case MODE_A: launch_rows<MODE_A, true>(rgA_, a, gridA_, blockA_, stream_, policy_); break;
+    case MODE_B: launch_rows<MODE_B, true>(rg_, a, gridB_, block_, stream_, policy_); break;
     default:
       if (ghost)
-        launch_rows<MODE_STENCIL, true>(rg_, a, grid_, block_, stream_);
+        launch_rows<MODE_STENCIL, true>(rg_, a, gridB_, block_, stream_);
       else
-        launch_rows<MODE_STENCIL, false>(rg_, a, grid_, block_, stream_);
+        launch_rows<MODE_STENCIL, false>(rg_, a, gridB_, block_, stream_);
     }
   }
   else
@@ -855,21 +927,21 @@ void Solver::launch_mode(int mode, bool ghost, const VecArgs &a)
     {
     case MODE_A:
       if (gh)
-        launch_scalar<MODE_A, true>(sg_, a, layout_, grid_, block_, stream_);
+        launch_scalar<MODE_A, true>(sg_, a, layout_, gridB_, block_, stream_);
       else
-        launch_scalar<MODE_A, false>(sg_, a, layout_, grid_, block_, stream_);
+        launch_scalar<MODE_A, false>(sg_, a, layout_, gridB_, block_, stream_);
       break;
     case MODE_B:
       if (gh)
-        launch_scalar<MODE_B, true>(sg_, a, layout_, grid_, block_, stream_);
+        launch_scalar<MODE_B, true>(sg_, a, layout_, gridB_, block_, stream_);
       else
-        launch_scalar<MODE_B, false>(sg_, a, layout_, grid_, block_, stream_);
+        launch_scalar<MODE_B, false>(sg_, a, layout_, gridB_, block_, stream_);
       break;
     default:
       if (gh)
-        launch_scalar<MODE_STENCIL, true>(sg_, a, layout_, grid_, block_, stream_);
+        launch_scalar<MODE_STENCIL, true>(sg_, a, layout_, gridB_, block_, stream_);
       else
-        launch_scalar<MODE_STENCIL, false>(sg_, a, layout_, grid_, block_, stream_);
+        launch_scalar<MODE_STENCIL, false>(sg_, a, layout_, gridB_, block_, stream_);
     }
   }
   CHECK(hipGetLastError());
@@ -1073,7 +1145,7 @@ void Solver::begin_local(const float *b_dev, float *x_dev)
     CHECK(hipMemcpyAsync(r_, b_dev, N_ * sizeof(float), hipMemcpyDeviceToDevice, stream_));
   // p_old of iteration 0 must be finite everywhere it is read: beta = 0 then gives p = r exactly
   CHECK(hipMemsetAsync(p0_base_, 0, buflen_ * sizeof(float), stream_));
-  launch_dot(r_, r_, Np_, partB_, grid_, stream_); // padding holds zeros
+  launch_dot(r_, r_, Np_, partB_, gridB_, stream_); // padding holds zeros; as many partials as kernel B writes
 }
 
 void Solver::reduce_partials(int which, double *out_dev)

@@ -130,12 +130,13 @@ private:
   int engine_ = ENGINE_SCALAR;
   int policy_ = POL_KEEP_R;
   int layout_ = LAYOUT_LEX;
-  RowsGeom rg_{};
-  PlanesGeom pg_{};
+  RowsGeom rg_{}, rgA_{};     // kernel B (and the plain stencil) / kernel A
+  PlanesGeom pg_{}, pgA_{};
   MortonGeom mg_{};
   int planes_r_ = 4;
   ScalarGeom sg_{};
-  int grid_ = 1, block_ = 256;
+  int grid_ = 1, block_ = 256;               // grid_: number of partial-sum addends = max(gridA_, gridB_)
+  int gridA_ = 1, gridB_ = 1, blockA_ = 256; // launch shapes of kernel A / kernel B
   // padded rows: a lexicographic grid whose axis 0 is not a multiple of 4 points is kept internally
   // with rows of s0_ = n0 rounded up to 4 floats (padding zero), so that the 16-byte engines apply;
   // b and x are copied in at begin_local() and x is copied back by finish()
