@@ -22,9 +22,6 @@ struct MortonGeom
   unsigned long long N;
   unsigned mmask[CG_MAXD];
   int interleave; // tile order of the tiled kernel: 0 contiguous range per workgroup, 1 XCD-chunked round-robin
-  // marching kernel (k_morton_march): the bits of the TILE index that belong to the marching axis, and the
-  // number of tiles along it (0: the marching kernel is not used)
-  unsigned march_mask, march_len;
 };
 
 template <int MODE, int POL>
@@ -311,214 +308,6 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
     }
     if (CG_MORTON_NBUF == 1)
       __syncthreads(); // the single buffer is overwritten by the next tile
-  }
-  if constexpr (MODE != MODE_STENCIL)
-    block_write_partial(acc, a.part_out, sh);
-}
-
-// ---- marching variant ----------------------------------------------------------------------
-//
-// The tiles of the Z-curve form columns along the last axis (the tiles that agree in every tile-index bit of
-// the other axes).  A workgroup walks a column with three consecutive tiles in LDS -- the one it computes and
-// its two neighbours along the marching axis -- so the two faces of that axis, a quarter of a 4-D tile's
-// faces, never leave LDS; the tile two steps ahead is in flight in registers meanwhile.  The faces of the other
-// axes are loaded from memory at use, as in k_morton_tile.  Columns are dealt to the XCDs in contiguous
-// ranges of the column number (itself a Z-curve over the other axes), whose workgroups walk neighbouring
-// columns side by side, so those faces meet in that XCD's L2.
-#ifndef CG_MARCH_TILE_BITS_DEF
-#define CG_MARCH_TILE_BITS_DEF 13
-#endif
-#ifndef CG_MARCH_BT
-#define CG_MARCH_BT 512
-#endif
-constexpr unsigned CG_MARCH_TILE_BITS = CG_MARCH_TILE_BITS_DEF;
-constexpr unsigned CG_MARCH_TILE = 1u << CG_MARCH_TILE_BITS;
-constexpr size_t CG_MARCH_LDS_BYTES = 3u * CG_MARCH_TILE * sizeof(float);
-
-template <int MODE, int POL>
-__global__ void __launch_bounds__(CG_MARCH_BT) k_morton_march(const MortonGeom g, const VecArgs a)
-{
-  __shared__ double sh[CG_MARCH_BT / 64 < 8 ? 8 : CG_MARCH_BT / 64];
-  extern __shared__ float4 march_lds[]; // [3][CG_MARCH_TILE / 4]
-  constexpr bool NT = POL == POL_KEEP_R;
-  constexpr unsigned QT = CG_MARCH_TILE / 4;        // quads per tile
-  constexpr int QPT = (int)(QT / CG_MARCH_BT);      // quads per thread and tile
-  constexpr unsigned NONE = 0xffffffffu;
-  Src<MODE, POL_PLAIN> src;
-  float *__restrict__ p_new = nullptr;
-  float coef = 0;
-  if constexpr (MODE == MODE_A)
-  {
-    const IterCtl c = prologue_A(a, sh);
-    if (!c.active)
-      return;
-    src.p = (c.k & 1) ? a.p1 : a.p0;
-    p_new = (c.k & 1) ? a.p0 : a.p1;
-    src.r = a.r;
-    src.beta = c.coef;
-  }
-  else if constexpr (MODE == MODE_B)
-  {
-    const IterCtl c = prologue_B(a, sh);
-    if (!c.active)
-      return;
-    src.p = (c.k & 1) ? a.p0 : a.p1;
-    coef = c.coef;
-  }
-  else
-  {
-    src.p = a.u;
-  }
-  const float alpha = coef;
-  float acc = 0;
-  const float4 zero4 = make_float4(0, 0, 0, 0);
-  const unsigned N = (unsigned)g.N;
-  const unsigned ntiles = N >> CG_MARCH_TILE_BITS;
-  const unsigned mm = g.march_mask, nk = g.march_len;
-  const unsigned ncols = ntiles / nk;
-  const unsigned m0 = g.mmask[0], m1 = g.mmask[1];
-  unsigned c0 = blockIdx.x, c1 = ncols, cstep = gridDim.x;
-  if (gridDim.x % 8 == 0 && ncols % 8 == 0)
-  {
-    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per = gridDim.x >> 3, chunk = ncols >> 3;
-    c0 = xcd * chunk + j;
-    c1 = (xcd + 1) * chunk;
-    cstep = per;
-  }
-
-  for (unsigned col = c0; col < c1; col += cstep)
-  {
-    const unsigned tb = pdep32(col, ~mm & (ntiles - 1u));
-    auto tile_of = [&](unsigned k) { return tb | pdep32(k, mm); };
-    auto slot = [&](unsigned k) -> float4 * { return march_lds + (size_t)(k % 3u) * QT; };
-    // tiles 0 and 1 of the column
-    for (unsigned k = 0; k < 2u && k < nk; k++)
-    {
-      const unsigned base = tile_of(k) << CG_MARCH_TILE_BITS;
-      float4 *b = slot(k);
-#pragma unroll
-      for (int s = 0; s < QPT; s++)
-      {
-        const unsigned ql = threadIdx.x + (unsigned)CG_MARCH_BT * s;
-        b[ql] = src.ld4((long long)(base + (ql << 2)));
-      }
-    }
-    __syncthreads();
-
-    for (unsigned k = 0; k < nk; k++)
-    {
-      const unsigned t = tile_of(k);
-      const unsigned tp = k > 0 ? tile_of(k - 1u) : NONE;
-      const unsigned tn = k + 1u < nk ? tile_of(k + 1u) : NONE;
-      const unsigned base = t << CG_MARCH_TILE_BITS;
-      const float4 *cur = slot(k), *prv = slot(k + 2u), *nxt = slot(k + 1u); // (k - 1) % 3 == (k + 2) % 3
-      // the tile two steps ahead travels in registers while this one is computed
-      const bool ahead = k + 2u < nk;
-      float4 nx[QPT];
-      if (ahead)
-      {
-        const unsigned base2 = tile_of(k + 2u) << CG_MARCH_TILE_BITS;
-#pragma unroll
-        for (int s = 0; s < QPT; s++)
-          nx[s] = src.ld4((long long)(base2 + ((threadIdx.x + (unsigned)CG_MARCH_BT * s) << 2)));
-      }
-      float4 xv[QPT], rv[QPT];
-      if constexpr (MODE == MODE_B)
-      {
-#pragma unroll
-        for (int s = 0; s < QPT; s++)
-        {
-          const unsigned i = base + ((threadIdx.x + (unsigned)CG_MARCH_BT * s) << 2);
-          xv[s] = load4<NT>(a.x + i);
-          rv[s] = load4<false>(a.r + i);
-        }
-      }
-
-      // quad holding index j: one of the three tiles in LDS, memory otherwise, zero outside the grid
-      auto quad = [&](unsigned j) -> float4 {
-        float4 v = zero4;
-        const unsigned tj = j >> CG_MARCH_TILE_BITS, ql = (j & (CG_MARCH_TILE - 1u)) >> 2;
-        if (tj == t)
-          v = cur[ql];
-        else if (tj == tn)
-          v = nxt[ql];
-        else if (tj == tp)
-          v = prv[ql];
-        else if (j < N)
-          v = src.ld4((long long)(j & ~3u));
-        return v;
-      };
-
-#pragma unroll
-      for (int s = 0; s < QPT; s++)
-      {
-        const unsigned ql = threadIdx.x + (unsigned)CG_MARCH_BT * s;
-        const unsigned i = base + (ql << 2);
-        const float4 cc = cur[ql];
-        const float4 xp = quad(morton_up(i + 1u, m0, N));
-        const float4 xm = quad(morton_dn(i, m0, N));
-        const float4 yp = quad(morton_up(i + 2u, m1, N));
-        const float4 ym = quad(morton_dn(i, m1, N));
-        float4 lv;
-        lv.x = 0.0f + axis_term(cc.y, cc.x, xm.y);
-        lv.y = 0.0f + axis_term(xp.x, cc.y, cc.x);
-        lv.z = 0.0f + axis_term(cc.w, cc.z, xm.w);
-        lv.w = 0.0f + axis_term(xp.z, cc.w, cc.z);
-        lv.x += axis_term(cc.z, cc.x, ym.z);
-        lv.y += axis_term(cc.w, cc.y, ym.w);
-        lv.z += axis_term(yp.x, cc.z, cc.x);
-        lv.w += axis_term(yp.y, cc.w, cc.y);
-        for (int ax = 2; ax < g.d; ax++)
-        {
-          const unsigned m = g.mmask[ax];
-          const float4 up = quad(morton_up(i, m, N));
-          const float4 um = quad(morton_dn(i, m, N));
-          lv.x += axis_term(up.x, cc.x, um.x);
-          lv.y += axis_term(up.y, cc.y, um.y);
-          lv.z += axis_term(up.z, cc.z, um.z);
-          lv.w += axis_term(up.w, cc.w, um.w);
-        }
-        if constexpr (MODE == MODE_STENCIL)
-        {
-          store4<false>(a.out + i, lv);
-        }
-        else if constexpr (MODE == MODE_A)
-        {
-          store4<NT>(p_new + i, cc);
-          acc = fmaf(cc.x, lv.x, acc);
-          acc = fmaf(cc.y, lv.y, acc);
-          acc = fmaf(cc.z, lv.z, acc);
-          acc = fmaf(cc.w, lv.w, acc);
-        }
-        else
-        {
-          float4 xo = xv[s], ro = rv[s];
-          xo.x = fmaf(alpha, cc.x, xo.x);
-          xo.y = fmaf(alpha, cc.y, xo.y);
-          xo.z = fmaf(alpha, cc.z, xo.z);
-          xo.w = fmaf(alpha, cc.w, xo.w);
-          ro.x = fmaf(-alpha, lv.x, ro.x);
-          ro.y = fmaf(-alpha, lv.y, ro.y);
-          ro.z = fmaf(-alpha, lv.z, ro.z);
-          ro.w = fmaf(-alpha, lv.w, ro.w);
-          store4<NT>(a.x + i, xo);
-          store4<false>(a.r + i, ro);
-          acc = fmaf(ro.x, ro.x, acc);
-          acc = fmaf(ro.y, ro.y, acc);
-          acc = fmaf(ro.z, ro.z, acc);
-          acc = fmaf(ro.w, ro.w, acc);
-        }
-      }
-      __syncthreads(); // everybody is done with the tile behind: its slot takes the tile two steps ahead
-      if (ahead)
-      {
-        float4 *dst = slot(k + 2u);
-#pragma unroll
-        for (int s = 0; s < QPT; s++)
-          dst[threadIdx.x + (unsigned)CG_MARCH_BT * s] = nx[s];
-      }
-      __syncthreads();
-    }
   }
   if constexpr (MODE != MODE_STENCIL)
     block_write_partial(acc, a.part_out, sh);

@@ -365,28 +365,6 @@ static void make_morton_geom(int d, unsigned long long N, MortonGeom &g, int &bl
   // with at least one LDS tile per workgroup the tiled kernel is used: never more workgroups than tiles
   if (N % CG_MORTON_TILE == 0 && N / CG_MORTON_TILE >= 64)
     grid = (int)std::min<unsigned long long>((unsigned long long)grid, N / CG_MORTON_TILE);
-  // large grids: columns of tiles along the last axis, three tiles in LDS (k_morton_march); one workgroup
-  // per CU (96 KiB of LDS each)
-  if (env_int("CG_MORTON_MARCH", 0) && N % CG_MARCH_TILE == 0 && N < (1ull << 32))
-  {
-    const unsigned ntiles = (unsigned)(N >> CG_MARCH_TILE_BITS);
-    const unsigned mm = ntiles ? (g.mmask[d - 1] >> CG_MARCH_TILE_BITS) & (ntiles - 1u) : 0u;
-    const unsigned len = 1u << __builtin_popcount(mm);
-    if (ntiles >= 512 && len >= 4 && ntiles / len >= 64)
-    {
-      int dev = 0, cus = 256;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        cus = prop.multiProcessorCount;
-      (void)hipGetLastError();
-      g.march_mask = mm;
-      g.march_len = len;
-      const unsigned ncols = ntiles / len;
-      const unsigned want = (unsigned)std::max(8, cus * std::max(1, env_int("CG_MORTON_MARCH_BPCU", 1)) / 8 * 8);
-      grid = (int)std::min(want, ncols / 8 * 8);
-      block = CG_MARCH_BT;
-    }
-  }
 }
 
 size_t Solver::plane_of(const SolverDesc &d)
@@ -711,8 +689,6 @@ const char *Solver::kernel_name() const
   case ENGINE_ROWS: return rg_.R ? "k_cols" : "k_rows";
   case ENGINE_PLANES: return "k_planes";
   case ENGINE_MORTON4: // the same rule as launch_morton4
-    if (mg_.march_len)
-      return "k_morton_march";
     return (mg_.N >= (unsigned long long)CG_MORTON_TILE * gridB_ && mg_.N % CG_MORTON_TILE == 0 && env_int("CG_MORTON_TILED", 1))
                ? "k_morton_tile"
                : "k_morton4";
@@ -833,30 +809,9 @@ static void launch_planes(const PlanesGeom &g, const VecArgs &a, int grid, int b
     launch_planes_pol<MODE, GHOST, POL_PLAIN>(g, a, grid, block, R, s);
 }
 
-template <int MODE, int POL>
-static void launch_morton_march(const MortonGeom &g, const VecArgs &a, int grid, hipStream_t s)
-{
-  static bool sized = false; // per instantiation: the kernel may use more than the default 64 KiB of LDS
-  if (!sized)
-  {
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_morton_march<MODE, POL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_MARCH_LDS_BYTES));
-    sized = true;
-  }
-  hipLaunchKernelGGL((k_morton_march<MODE, POL>), dim3(grid), dim3(CG_MARCH_BT), CG_MARCH_LDS_BYTES, s, g, a);
-}
-
 template <int MODE>
 static void launch_morton4(const MortonGeom &g, const VecArgs &a, int grid, int block, hipStream_t s, int pol = POL_PLAIN)
 {
-  if (g.march_len)
-  {
-    if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
-      launch_morton_march<MODE, POL_KEEP_R>(g, a, grid, s);
-    else
-      launch_morton_march<MODE, POL_PLAIN>(g, a, grid, s);
-    return;
-  }
   // grids of at least one tile per workgroup use the LDS-tiled kernel
   const bool tiled = g.N >= (unsigned long long)CG_MORTON_TILE * grid && g.N % CG_MORTON_TILE == 0 &&
                      env_int("CG_MORTON_TILED", 1);
