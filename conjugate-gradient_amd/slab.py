@@ -58,7 +58,8 @@ class HipSlabOps:
                                       r_buf=self.r_buf.data_ptr(), p0_buf=self.p0_buf.data_ptr(),
                                       p1_buf=self.p1_buf.data_ptr())
         self.solver.bind_partials(self.parts[0].data_ptr(), self.parts[1].data_ptr())
-        self.nparts = self.solver.blocks
+        self.blocks = self.solver.blocks     # partial sums this rank's kernels write
+        self.nparts = self.blocks            # ... and the number every rank reduces
 
     def set_nparts(self, n):
         """Ranks whose slabs differ in shape own different numbers of workgroups; all of them reduce
@@ -86,7 +87,11 @@ class HipSlabOps:
         self.solver.begin(b.data_ptr(), x.data_ptr(), rel, lagged)
 
     def sum_tensor(self, which):
-        """The tensor whose element-wise sum over ranks the next kernel consumes."""
+        """The tensor whose element-wise sum over ranks the next kernel consumes.  The kernels write this
+        rank's `blocks` partial sums; the rest of a longer common array holds the previous reduction's
+        result and is cleared here, before the next in-place reduction adds it up again."""
+        if self.nparts > self.blocks:
+            self.parts[which, self.blocks:self.nparts].zero_()
         return self.parts[which, :self.nparts]
 
     def init_state(self, rel, lagged, maxit):

@@ -13,18 +13,26 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def run_virtual(pkg, lib, L, d, nranks, b, iters, engine=0):
+def run_virtual(pkg, lib, L, d, nranks, b, iters, engine=0, heights=None):
     from conjugate_gradient_amd.slab import HipSlabOps
     dev = torch.device("cuda", 0)
-    h = L // nranks
-    ext = [L] * (d - 1) + [h]
-    n_loc = (L ** d) // nranks
-    slabs, xs, bs = [], [], []
+    heights = heights or [L // nranks] * nranks
+    assert sum(heights) == L and len(heights) == nranks
+    plane = L ** (d - 1)
+    slabs, xs, bs, n_locs = [], [], [], []
     for r in range(nranks):
+        ext = [L] * (d - 1) + [heights[r]]
+        n_loc, first = heights[r] * plane, sum(heights[:r]) * plane
         o = HipSlabOps(lib, ext, int(r > 0), int(r < nranks - 1), dev)
         slabs.append(o)
-        bs.append(torch.from_numpy(b[r * n_loc:(r + 1) * n_loc].copy()).cuda())
+        n_locs.append(n_loc)
+        bs.append(torch.from_numpy(b[first:first + n_loc].copy()).cuda())
         xs.append(torch.zeros(n_loc, dtype=torch.float32, device=dev))
+    # slabs of different shape launch different numbers of workgroups: every rank reduces the largest count
+    most = max(o.nparts for o in slabs)
+    for o in slabs:
+        if o.nparts != most:
+            o.set_nparts(most)
 
     def sync():
         torch.cuda.synchronize()
@@ -39,13 +47,15 @@ def run_virtual(pkg, lib, L, d, nranks, b, iters, engine=0):
     def exchange():
         sync()
         for r, o in enumerate(slabs):
-            g, n, pl = o.ghost_offset, n_loc, o.plane
+            g, n, pl = o.ghost_offset, n_locs[r], o.plane
             if r > 0:
                 lo = slabs[r - 1]
-                o.r_buf[g - pl:g] = lo.r_buf[g + n - pl:g + n]
+                glo, nlo = lo.ghost_offset, n_locs[r - 1]
+                o.r_buf[g - pl:g] = lo.r_buf[glo + nlo - pl:glo + nlo]
             if r < nranks - 1:
                 hi = slabs[r + 1]
-                o.r_buf[g + n:g + n + pl] = hi.r_buf[g:g + pl]
+                ghi = hi.ghost_offset
+                o.r_buf[g + n:g + n + pl] = hi.r_buf[ghi:ghi + pl]
         sync()
 
     for o, bb, xx in zip(slabs, bs, xs):
@@ -88,6 +98,26 @@ def test_virtual_ranks_match_single_gpu_and_oracle(pkg, lib, oracle, engine_env,
     _, it1, h1 = lib.conjugate_gradient_gpu_ex(bd.data_ptr(), x1.data_ptr(), L, d, hist_len=200)
     assert abs(iters - it1) <= max(2, 0.05 * it1)
     assert np.linalg.norm(x - x1.cpu().numpy()) <= 1e-5 * np.linalg.norm(xe)
+    n = min(len(hist), len(h1), 8)
+    assert np.allclose(hist[:n], h1[:n], rtol=1e-5)
+
+
+@pytest.mark.parametrize("L,d,heights", [(16, 3, [6, 10]), (64, 2, [10, 30, 24]), (32, 3, [4, 20, 8])])
+def test_virtual_ranks_of_unequal_height(pkg, lib, oracle, engine_env, L, d, heights):
+    """Slabs of different heights launch different numbers of workgroups, so their arrays of partial sums
+    differ in length; every rank reduces the longest (cg_solver_bind_partials_n) and the solve agrees with
+    one solver on the whole grid."""
+    N = L ** d
+    rng = np.random.default_rng(3 * L + d)
+    xt = rng.random(N).astype(np.float32)
+    b = oracle.laplace_f32(xt, d, L)
+    x, iters, hist = run_virtual(pkg, lib, L, d, len(heights), b, 200, heights=heights)
+    assert np.all(np.abs(x - xt) < 1e-3)
+    x1 = torch.zeros(N, dtype=torch.float32, device="cuda")
+    bd = torch.from_numpy(b).cuda()
+    _, it1, h1 = lib.conjugate_gradient_gpu_ex(bd.data_ptr(), x1.data_ptr(), L, d, hist_len=200)
+    assert abs(iters - it1) <= max(2, 0.05 * it1)
+    assert np.linalg.norm(x - x1.cpu().numpy()) <= 1e-5 * np.linalg.norm(x)
     n = min(len(hist), len(h1), 8)
     assert np.allclose(hist[:n], h1[:n], rtol=1e-5)
 
