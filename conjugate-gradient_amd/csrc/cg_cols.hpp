@@ -37,11 +37,8 @@ namespace cgamd
 // Exact rows (g.xl, both kernels through LDS): a row whose n0/4 lanes are not a power of two would idle up
 // to half of its slot; instead it takes exactly n0/4 lanes, rows cross wave boundaries, and the x
 // neighbours of a lane come from LDS as well instead of from lane shifts.
-#ifndef COLS_A_WAVES
-#define COLS_A_WAVES 0
-#endif
 template <int MODE, bool GHOST, int D, int R, bool STREAM, bool LDS>
-__global__ void __launch_bounds__(512, (MODE == MODE_A && COLS_A_WAVES) ? COLS_A_WAVES : 1) k_cols(const RowsGeom g, const VecArgs a)
+__global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LDS) ? 4 : 1) k_cols(const RowsGeom g, const VecArgs a)
 {
   __shared__ float4 hand[LDS ? 2 * R * 512 : 1];
   static_assert(D == 3 || D == 4 || D == 5, "columns in blocks: d = 3, 4 and 5");
@@ -211,7 +208,13 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && COLS_A_WAVES) ? COLS_A
       }
     }
 
-    Nb nb0 = ldnb(y0), nb1 = ldnb(y0 + 1);
+    // Depth of the neighbour pipeline: the neighbours of rows y, y+1, y+2 in flight, or (kernel A of large 4-D
+    // grids) only of y and y+1.  Kernel A loads every neighbour twice (r and p), so the deep pipeline cost it 155
+    // VGPRs and left one 512-lane workgroup per CU; the shallow one fits 128 (two workgroups per CU, as the
+    // launch bounds above demand: 8 bytes of spills per lane).  128^4: kernel A 744 -> 665 us, 96^4 317 -> 248,
+    // 64^3 x 512 360 -> 340; 3-D and 5-D grids and grids the caches hold lose a few percent and keep the deep one.
+    constexpr bool SHALLOW = (MODE == MODE_A) && D == 4 && STREAM;
+    Nb nb0 = ldnb(y0), nb1 = SHALLOW ? nb0 : ldnb(y0 + 1);
 
     for (long long y = y0; y < y1; y++)
     {
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && COLS_A_WAVES) ? COLS_A
           }
         }
       }
-      const Nb nb2 = ldnb(y + 2);
+      const Nb nb2 = ldnb(SHALLOW ? y + 1 : y + 2);
       float4 bm = nb0.bm, bp = nb0.bp;
       if constexpr (LDS)
       {
@@ -379,8 +382,13 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && COLS_A_WAVES) ? COLS_A
         xv[j] = xn[j];
         rv[j] = rn[j];
       }
-      nb0 = nb1;
-      nb1 = nb2;
+      if constexpr (SHALLOW)
+        nb0 = nb2;
+      else
+      {
+        nb0 = nb1;
+        nb1 = nb2;
+      }
     }
     if constexpr (MODE == MODE_A && GHOST)
     {
