@@ -1162,6 +1162,7 @@ void Solver::bind_links(int rank, int world, void *const *boxes)
     bind_sums(nullptr, 0, nullptr, 0);
     return;
   }
+  CG_REQUIRE(!rccl_, "a communicator is bound: unbind it before binding boxes");
   CG_REQUIRE(world >= 1 && world <= CG_LINKS_MAX_RANKS, "direct links support 1..64 ranks");
   CG_REQUIRE(rank >= 0 && rank < world, "rank out of range");
   CG_REQUIRE((desc_.has_lo != 0) == (rank > 0) && (desc_.has_hi != 0) == (rank + 1 < world),

@@ -911,3 +911,46 @@ def test_hypercube_of_two_points_per_axis_runs_on_the_quad_kernels(lib, monkeypa
         s.close()
     assert np.allclose(outs[0][1], outs[1][1], rtol=1e-5)
     assert rel_l2(outs[0][0], outs[1][0]) <= 1e-5
+
+
+def test_solve_is_ordered_after_the_default_stream(lib):
+    """The reference runs everything on the default stream (conjugate-gradient_gpu.cu:327-376), so a
+    right-hand side still being produced there when the solver is called is implicitly waited for.  Here
+    the solver has a private stream: the entry points must make it wait.  A long chain of default-stream
+    work ends with the copy that puts the real right-hand side into b; the call follows without any
+    synchronisation and must see that b, not the zeros before it."""
+    L, d = 512, 2
+    N = L ** d
+    g = torch.Generator(device="cuda").manual_seed(3)
+    want = torch.rand(N, device="cuda", generator=g)
+    x_ref = torch.zeros(N, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    res_ref, it_ref, _ = lib.conjugate_gradient_gpu_ex(want.data_ptr(), x_ref.data_ptr(), L, d, maxit=30)
+    b = torch.zeros(N, dtype=torch.float32, device="cuda")
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    big = torch.rand(4096, 4096, device="cuda", generator=g)
+    torch.cuda.synchronize()
+    acc = big
+    for _ in range(40):                     # tens of milliseconds of queued default-stream work
+        acc = (acc @ big) * 1e-3
+    b.copy_(want + 0.0 * acc[0, 0])         # depends on the whole chain
+    res, it, _ = lib.conjugate_gradient_gpu_ex(b.data_ptr(), x.data_ptr(), L, d, maxit=30)
+    assert it == it_ref == 30 and res == res_ref
+    assert torch.equal(x, x_ref)
+
+
+def test_history_of_a_solve_longer_than_the_device_ring(lib):
+    """The device keeps the last 1024 values of r.r; a longer solve is polled by the host, which keeps
+    every value, so the replayed per-iteration print-out (conjugate-gradient_gpu.cu:369) has no gaps."""
+    L, d = 1024, 2
+    N = L ** d
+    b = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(b.data_ptr(), N, 21)
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    res, iters, hist = lib.conjugate_gradient_gpu_ex(b.data_ptr(), x.data_ptr(), L, d, maxit=1500, rel=1e-9, hist_len=1500)
+    assert iters == 1500 and len(hist) == 1500
+    h = np.array(hist)
+    assert np.all(np.isfinite(h)) and np.all(h > 0)
+    assert h[0] == np.float32(np.sqrt(np.float64(np.float32((b.double() @ b.double()).item()))))
+    assert h[-1] < 1e-2 * h[0]
