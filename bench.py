@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--no-beyond-cache", action="store_true",
                     help="skip the second, larger 2-D workload whose vectors exceed the Infinity Cache")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--probe-child", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--no-sandbox", action="store_true",
+                    help="probe the multi-rank transports in this process instead of in child processes")
     return ap.parse_args()
 
 
@@ -422,6 +425,128 @@ def cpu_baselines_isolated(ext, budget_s):
     return {"cpu_baseline": {"value": None, "unit": "iterations/s", "cores": 1, "kind": "port", "sample": "failed: " + err}}
 
 
+def slab_probe(s, b, x, barrier, rank, world, n=30):
+    """A short timed run on the slab driver's current transport: (seconds for n iterations, max over
+    ranks; residual history of the first three iterations; the ranks' error messages, empty if none).
+    Every rank makes the same collective calls whatever fails on one of them."""
+    import torch.distributed as dist
+    x.zero_()
+    barrier()
+    s.begin(b, x, 0.0, 1)
+    s.iterate(3)
+    s.sync()
+    barrier()
+    t0 = time.perf_counter()
+    s.iterate(n)
+    s.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    err, hist = "", []
+    try:
+        _, _, hist = s.finish(hist_len=3)
+    except RuntimeError as e:
+        err = f"rank {rank}: {e}"
+    seen = [None] * world
+    if world > 1:
+        dist.all_gather_object(seen, (dt, err))
+    else:
+        seen = [(dt, err)]
+    return max(t for t, _ in seen), hist, "; ".join(e for _, e in seen if e)
+
+
+def check_candidate(s, name, hist_c, b, x, barrier, rank, world):
+    """Set transport `name` ("rccl" | "links") up, run the probe on it, compare with the collectives'
+    residual history hist_c and the neighbours' boundary planes, and take it down again.
+    Returns (usable on every rank, probe seconds, reason if not usable).  Collective."""
+    up = s.enable_rccl() if name == "rccl" else s.enable_links()
+    if not up:
+        return False, None, (s.rccl_reason if name == "rccl" else s.links_reason) or "could not be set up"
+    t_new, hist_n, err_n = slab_probe(s, b, x, barrier, rank, world)
+    ok = int(not err_n and len(hist_n) == 3 and all(abs(a - c) <= 1e-5 * abs(c) for a, c in zip(hist_n, hist_c)))
+    why = "" if ok else (err_n or f"self-check mismatch {hist_n} vs {hist_c}")
+    mine = ok
+    ok = s._all_agree(ok)
+    if mine and not ok:
+        why = "self-check failed on another rank"
+    if ok and not s._all_agree(s.ghosts_match_neighbours()):
+        ok, why = False, "ghost planes differ from the neighbours' boundary planes"
+    if name == "rccl":
+        s.disable_rccl()
+    else:
+        s.disable_links()
+    return bool(ok), t_new, why
+
+
+def probe_child(args):
+    """`--probe-child NAME`: the sandbox of one transport.  A process group of its own (the parent passes a
+    different MASTER_PORT), the slab driver on the same workload, the collectives' probe and then
+    check_candidate(NAME).  A transport that aborts or hangs does so here, not in the benchmark process,
+    which only uses what came back clean from every rank.  Prints one line "PROBE_RESULT {json}"."""
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("CG_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group(args.backend)
+    lib = load_package().load_library()
+    ext, _ = workload_extents(args.workload)
+    if args.scaling == "strong" and world > 1:
+        ext = ext[:-1] + [ext[-1] // world]
+    N = 1
+    for e in ext:
+        N *= e
+    from conjugate_gradient_amd.slab import SlabCG
+    b = torch.empty(N, dtype=torch.float32, device=device)
+    x = torch.zeros(N, dtype=torch.float32, device=device)
+    lib.c.cg_fill_uniform(C.c_void_p(b.data_ptr()), N, 1234 + rank)
+    torch.cuda.synchronize()
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    s = SlabCG(lib, ext, rank=rank, world=world, device=device)
+    t_coll, hist_c, err_c = slab_probe(s, b, x, barrier, rank, world)
+    if err_c:
+        out = {"ok": False, "why": "collectives probe failed: " + err_c}
+    else:
+        ok, t_new, why = check_candidate(s, args.probe_child, hist_c, b, x, barrier, rank, world)
+        out = {"ok": ok, "seconds": t_new, "collectives_seconds": t_coll, "why": why}
+    print("PROBE_RESULT " + json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def probe_in_sandbox(name, args, port_offset):
+    """Run probe_child(name) as a child process of this rank (every rank does; the children form their own
+    process group on MASTER_PORT + port_offset).  Returns (ok, seconds, why) of THIS rank's child; a child
+    that crashes, hangs (killed after 120 s) or prints nothing counts as not ok."""
+    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset))
+    # under torch.distributed.run the ranks are told to use the launcher's store on MASTER_PORT; the children
+    # rendezvous on a port of their own, so their rank 0 has to host the store itself
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+        del env[k]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--probe-child", name, "--workload", args.workload,
+           "--scaling", args.scaling, "--backend", args.backend, "--gpus", str(args.gpus)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("PROBE_RESULT "):
+                out = json.loads(line[len("PROBE_RESULT "):])
+                return bool(out.get("ok")), out.get("seconds"), out.get("why", "")
+        return False, None, f"child exit {r.returncode}: {(r.stderr or r.stdout)[-200:]}"
+    except subprocess.TimeoutExpired:
+        return False, None, "child timed out"
+    except Exception as e:  # noqa: BLE001
+        return False, None, repr(e)[:200]
+
+
 def main():
     args = parse()
     import torch
@@ -499,70 +624,39 @@ def main():
         s = SlabCG(lib, ext, rank=rank, world=world, device=device)
         comm, comm_note = "collectives", ""
 
-        def probe(n=30):
-            """A short timed run on the current transport: (seconds for n iterations, max over
-            ranks; residual history of the first three iterations; the ranks' error messages, empty
-            if none).  Every rank makes the same collective calls whatever fails on one of them."""
-            x.zero_()
-            barrier()
-            s.begin(b, x, 0.0, 1)
-            s.iterate(3)
-            s.sync()
-            barrier()
-            t0 = time.perf_counter()
-            s.iterate(n)
-            s.sync()
-            barrier()
-            dt = time.perf_counter() - t0
-            err, hist = "", []
-            try:
-                _, _, hist = s.finish(hist_len=3)
-            except RuntimeError as e:
-                err = f"rank {rank}: {e}"
-            seen = [None] * world
-            if world > 1:
-                dist.all_gather_object(seen, (dt, err))
-            else:
-                seen = [(dt, err)]
-            return max(t for t, _ in seen), hist, "; ".join(e for _, e in seen if e)
-
         # Transport: the library's own RCCL calls (graph-captured), the direct xGMI boxes, or the Python-driven
-        # collectives.  A candidate is used only if it could be set up on every rank, reproduces the
-        # collectives' residual history, delivers ghost planes that equal the neighbours' boundary planes
-        # bit for bit, and (with --comm auto) was the fastest in a 30-iteration probe.
+        # collectives.  A candidate is used only if it could be set up on every rank, reproduced the
+        # collectives' residual history, delivered ghost planes that equal the neighbours' boundary planes
+        # bit for bit, and (with --comm auto) was the fastest in a 30-iteration probe.  The candidates are
+        # tried in child processes first (probe_in_sandbox): a transport that aborts or hangs on this
+        # machine must not take the benchmark down with it.
         candidates = {"auto": ["rccl", "links"], "rccl": ["rccl"], "links": ["links"], "collectives": []}[args.comm]
         if args.backend != "nccl" and world > 1:
             candidates = [c for c in candidates if c != "rccl"]   # rehearsal backends share one GPU: RCCL refuses that
         probes = {}
         if candidates:
-            t_coll, hist_c, err_c = probe()
+            t_coll, hist_c, err_c = slab_probe(s, b, x, barrier, rank, world)
             if err_c:
                 raise SystemExit(f"probe over the collectives failed: {err_c}")
             probes["collectives"] = t_coll
             notes = []
-            for name in candidates:
-                up = s.enable_rccl() if name == "rccl" else s.enable_links()
-                if not up:
-                    notes.append(f"{name}: {s.rccl_reason if name == 'rccl' else s.links_reason}")
-                    continue
-                t_new, hist_n, err_n = probe()
-                ok = int(not err_n and len(hist_n) == 3 and
-                         all(abs(a - c) <= 1e-5 * abs(c) for a, c in zip(hist_n, hist_c)))
-                why = "" if ok else (err_n or f"self-check mismatch {hist_n} vs {hist_c}")
-                mine = ok
-                ok = s._all_agree(ok)
-                if mine and not ok:
-                    why = "self-check failed on another rank"
-                if ok and not s._all_agree(s.ghosts_match_neighbours()):
-                    ok, why = False, "ghost planes differ from the neighbours' boundary planes"
-                if ok:
+            for k, name in enumerate(candidates):
+                if args.no_sandbox:
+                    ok, t_new, why = check_candidate(s, name, hist_c, b, x, barrier, rank, world)
+                else:
+                    ok, t_new, why = probe_in_sandbox(name, args, 101 + 7 * k)
+                    seen = [None] * world
+                    if world > 1:
+                        dist.all_gather_object(seen, (ok, t_new, why))
+                    else:
+                        seen = [(ok, t_new, why)]
+                    ok = all(o for o, _, _ in seen)
+                    t_new = max((t for _, t, _ in seen if t is not None), default=None)
+                    why = "; ".join(sorted({w for o, _, w in seen if not o and w}))
+                if ok and t_new is not None:
                     probes[name] = t_new
                 else:
                     notes.append(f"{name}: {why}")
-                if name == "rccl":
-                    s.disable_rccl()
-                else:
-                    s.disable_links()
             usable = [c for c in candidates if c in probes]
             if args.comm == "auto":
                 pick = min(["collectives"] + usable, key=lambda c: probes[c])
@@ -678,5 +772,7 @@ def main():
 if __name__ == "__main__":
     if "--pmc-child" in sys.argv:
         pmc_child(parse())
+    elif "--probe-child" in sys.argv:
+        probe_child(parse())
     else:
         main()
