@@ -21,8 +21,11 @@ Bytes.  Three prices per grid point, always named:
              update 12), B 24 B, iteration 44 B.  roofline.achieved / roofline.frac use this price,
              so they can exceed the HBM peak: this design never stores A p and reads p once less.
   moved      what these kernels really stream: A 12 B (r, p_old in, p_new out), B 20 B (x, p, r in,
-             x, r out), iteration 32 B.  frac_moved is the bandwidth the memory system delivers --
-             at 8192^2 part of it from the 256 MiB Infinity Cache, which holds r.
+             x, r out), iteration 32 B.  With the paired x update (config.paired_x_update: kernel B of
+             an even iteration leaves x alone, the next one reads both p and applies both updates) a
+             pair of B launches moves 12 + 24 B: B 18 B on average, iteration 30 B.  frac_moved is the
+             bandwidth the memory system delivers -- at 8192^2 part of it from the 256 MiB Infinity
+             Cache, which holds r.
   counter    bytes leaving L2 per launch, measured in this run by two rocprofv3 --pmc passes
              (FETCH_SIZE doubled as the gfx950 counter reports half of wide reads, WRITE_SIZE as is);
              Infinity-Cache hits are included, so it bounds HBM traffic from above.  null when the
@@ -48,6 +51,12 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
 # bytes per grid point: "effective" = the specified three-kernel fusion, "moved" = what this design streams
 BYTES = {"A": {"effective": 20, "moved": 12}, "B": {"effective": 24, "moved": 20},
          "iter": {"effective": 44, "moved": 32}}
+# a solver that updates x every second iteration (two updates at once): B moves 12 and 24 B in turn
+BYTES_PAIRED = {"A": BYTES["A"], "B": {"effective": 24, "moved": 18}, "iter": {"effective": 44, "moved": 30}}
+
+
+def bytes_of(paired):
+    return BYTES_PAIRED if paired else BYTES
 BEYOND_CACHE_WORKLOAD = "16384x8192"   # 2^27 points: every vector is twice the Infinity Cache
 
 
@@ -135,8 +144,10 @@ def live_traffic(workload):
                     if m and m.group(1) in "12" and row.get("Counter_Name", counter) == counter:
                         per.setdefault("A" if m.group(1) == "1" else "B", []).append(float(row["Counter_Value"]))
             for k, v in per.items():
-                full = [x for x in v if x > 0.5 * max(v)]   # drop no-op launches
-                got[kind][k] = statistics.median(full) * 1024.0 * (2.0 if kind == "fetch" else 1.0)
+                # drop no-op launches; the mean, because with the paired x update kernel B's launches
+                # alternate between two traffic levels (six iterations: three of each)
+                full = [x for x in v if x > 0.2 * max(v)]
+                got[kind][k] = statistics.mean(full) * 1024.0 * (2.0 if kind == "fetch" else 1.0)
             if not per:
                 notes.append(f"{counter} pass: no kernel rows")
         except Exception as e:  # noqa: BLE001 -- the counters are optional evidence, never fatal
@@ -196,11 +207,11 @@ def run_single(lib, ext, mode, steps, warmup, repeats, graph, barrier, device):
     done, res, _ = s.finish()
     assert done == warmup + steps * repeats, (done, warmup, steps, repeats)
     # per-kernel device time: HIP events on the solver's stream, outside the timed regions
-    msA, msB = s.time_kernels(max(10, min(50, steps)))
-    name = s.kernel_name
+    msA, msB = s.time_kernels(max(10, min(50, steps)) // 2 * 2)   # whole pairs of the paired x update
+    name, paired = s.kernel_name, s.paired_x
     s.close()
     del b, x
-    return {"N": N, "times": times, "msA": msA, "msB": msB, "kernel": name, "residue": res}
+    return {"N": N, "times": times, "msA": msA, "msB": msB, "kernel": name, "residue": res, "paired_x": paired}
 
 
 def roofline_of(run, traffic=None, traffic_note=None, traffic_detail=None):
@@ -208,6 +219,7 @@ def roofline_of(run, traffic=None, traffic_note=None, traffic_detail=None):
     N, msA, msB = run["N"], run["msA"], run["msB"]
     dom, other = ("B", "A") if msB >= msA else ("A", "B")
     ms = {"A": msA, "B": msB}
+    BYTES = bytes_of(run.get("paired_x"))
 
     def rate(k, price):
         return BYTES[k][price] * N / (ms[k] * 1e-3) / 1e9
@@ -295,8 +307,9 @@ def run_mixed(args, lib, device):
     print(json.dumps(out), flush=True)
 
 
-def iteration_rates(N, its):
+def iteration_rates(N, its, paired=False):
     """Whole-iteration byte rates of `its` iterations/s on N points, both prices."""
+    BYTES = bytes_of(paired)
     eff = BYTES["iter"]["effective"] * N * its / 1e9
     mov = BYTES["iter"]["moved"] * N * its / 1e9
     return {"hbm_effective_GBps": round(eff, 1), "hbm_frac_effective": round(eff / HBM_PEAK_GBPS, 4),
@@ -599,6 +612,7 @@ def main():
         times, res = run["times"], run["residue"]
         traffic, tnote, tdetail = ({}, "counter passes skipped (--no-traffic)", {}) if args.no_traffic else live_traffic(args.workload)
         roof = roofline_of(run, traffic, tnote, tdetail)
+        paired = run["paired_x"]
         if not args.no_beyond_cache and args.workload == "2d-8192":
             # the same kernels on a 2-D grid whose vectors are twice the Infinity Cache: the HBM-bound rate
             ext2, mode2 = workload_extents(BEYOND_CACHE_WORKLOAD)
@@ -612,7 +626,7 @@ def main():
                  "ms_per_step_min_max": [round(min(run2["times"]) / args.steps * 1e3, 5),
                                          round(max(run2["times"]) / args.steps * 1e3, 5)],
                  "roofline": roofline_of(run2, None, "not collected for this workload")},
-                **iteration_rates(run2["N"], its2))
+                **iteration_rates(run2["N"], its2, run2["paired_x"]))
         parallelism = "single"
     else:
         from conjugate_gradient_amd.slab import SlabCG
@@ -709,23 +723,27 @@ def main():
         parallelism = f"slab{world}"
         if comm != "collectives":
             with s._ctx():
-                msA, msB = s.ops.solver.time_kernels(max(10, min(50, args.steps)))
+                msA, msB = s.ops.solver.time_kernels(max(10, min(50, args.steps)) // 2 * 2)
                 s.sync()
             xA, xB = s.ops.solver.links_times()
             exchange = {"after_A": round(xA, 5), "after_B": round(xB, 5)}
         else:
             # over the collectives the kernels cannot be timed in place without the all-reduces between
             # them: time the same two kernels on this rank's slab with a stand-alone solver
+            os.environ["CG_XDEFER"] = "0"     # as the step interface runs them: x updated by every kernel B
             t = lib.make_solver(ext, index_mode=mode)
+            os.environ.pop("CG_XDEFER")
             x.zero_()
             torch.cuda.synchronize()
             t.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
             t.iterate(5, use_graph=False)
-            msA, msB = t.time_kernels(max(10, min(50, args.steps)))
+            msA, msB = t.time_kernels(max(10, min(50, args.steps)) // 2 * 2)
             t.close()
             exchange = None
-        roof = roofline_of({"N": N, "msA": msA, "msB": msB, "kernel": s.ops.solver.kernel_name}, None,
-                           "not collected in multi-rank runs")
+        # the step interface the Python-driven collectives use updates x in every kernel B
+        paired = s.ops.solver.paired_x and comm != "collectives"
+        roof = roofline_of({"N": N, "msA": msA, "msB": msB, "kernel": s.ops.solver.kernel_name, "paired_x": paired},
+                           None, "not collected in multi-rank runs")
         roof["exchange_ms"] = exchange
         roof["rank"] = 0
 
@@ -750,14 +768,14 @@ def main():
                        "points_per_gpu": N, "parallelism": parallelism, "graph": not args.no_graph,
                        "backend": args.backend if world > 1 else None,
                        "comm": (comm + (f" ({comm_note})" if comm_note else "")) if parallelism != "single" else None,
-                       "rhs": "u01 seed 1234+rank", "x0": 0},
+                       "paired_x_update": bool(paired), "rhs": "u01 seed 1234+rank", "x0": 0},
             "timing": {"regions": args.repeats, "statistic": "median",
                        "ms_per_step_min_max": [round(min(times) / args.steps * 1e3, 5), round(max(times) / args.steps * 1e3, 5)],
                        "ms_per_step_all": [round(t / args.steps * 1e3, 5) for t in times]},
             "iterations_per_sec_global": round(its, 3),
             "final_residue": res,
         }
-        out.update(iteration_rates(N * world, its))   # all ranks' points move once per global iteration
+        out.update(iteration_rates(N * world, its, paired))   # all ranks' points move once per global iteration
         out.update(extra)
         if roof:
             out["roofline"] = roof

@@ -20,7 +20,7 @@ EXPORTS = [
     "cg_eigen_extremes_gpu", "cg_two_grid_gpu", "cg_two_grid_pcg_gpu", "cg_multigrid_gpu",
     "cg_laplace_device", "cg_fill_uniform", "cg_u01_host", "cg_strong_scaling_events", "cg_laplace_time_events",
     "cg_solver_buffer_len", "cg_solver_ghost_offset", "cg_solver_plane", "cg_solver_create",
-    "cg_solver_destroy", "cg_solver_engine", "cg_solver_blocks", "cg_solver_kernel_name", "cg_solver_begin", "cg_solver_iterate",
+    "cg_solver_destroy", "cg_solver_engine", "cg_solver_blocks", "cg_solver_paired_x", "cg_solver_kernel_name", "cg_solver_begin", "cg_solver_iterate",
     "cg_solver_finish", "cg_solver_sync", "cg_solver_time_kernels", "cg_solver_begin_local",
     "cg_solver_reduce", "cg_solver_bind_sums", "cg_solver_bind_partials", "cg_solver_init_state", "cg_solver_add_iterations",
     "cg_solver_kernel_A", "cg_solver_kernel_B", "cg_solver_r", "cg_solver_p",
@@ -114,7 +114,7 @@ class Library:
         c.cg_solver_create.restype = C.c_void_p
         c.cg_solver_destroy.argtypes = [vp]
         c.cg_solver_destroy.restype = None
-        for f in ("cg_solver_engine", "cg_solver_blocks"):
+        for f in ("cg_solver_engine", "cg_solver_blocks", "cg_solver_paired_x"):
             getattr(c, f).argtypes = [vp]
             getattr(c, f).restype = i32
         c.cg_solver_kernel_name.argtypes = [vp]
@@ -389,6 +389,11 @@ class Solver:
     @property
     def blocks(self):
         return self.lib.c.cg_solver_blocks(self.h)
+
+    @property
+    def paired_x(self):
+        """True if cg_solver_iterate updates x every second iteration (two updates at once, same bits)."""
+        return bool(self.lib.c.cg_solver_paired_x(self.h))
 
     def begin(self, b, x, rel=1e-6, lagged=1):
         self.lib.c.cg_solver_begin(self.h, _ptr(b), _ptr(x), rel, lagged)

@@ -511,6 +511,7 @@ extern "C" cg_solver *cg_solver_create(const cg_solver_desc *desc) { return new 
 extern "C" void cg_solver_destroy(cg_solver *s) { delete s; }
 extern "C" int cg_solver_engine(const cg_solver *s) { return s->impl.engine(); }
 extern "C" int cg_solver_blocks(const cg_solver *s) { return s->impl.blocks(); }
+extern "C" int cg_solver_paired_x(const cg_solver *s) { return s->impl.paired_x() ? 1 : 0; }
 extern "C" const char *cg_solver_kernel_name(const cg_solver *s) { return s->impl.kernel_name(); }
 
 extern "C" void cg_solver_begin(cg_solver *s, const float *b, float *x, double rel, int lagged)
@@ -550,7 +551,7 @@ extern "C" void cg_solver_init_state(cg_solver *s, double rel, int lagged, int m
 }
 extern "C" void cg_solver_add_iterations(cg_solver *s, int n) { s->impl.add_iterations(n); }
 extern "C" void cg_solver_kernel_A(cg_solver *s) { s->impl.launch_A(); }
-extern "C" void cg_solver_kernel_B(cg_solver *s) { s->impl.launch_B(); }
+extern "C" void cg_solver_kernel_B(cg_solver *s) { s->impl.launch_B(false); } // x complete after every call
 extern "C" float *cg_solver_r(cg_solver *s) { return s->impl.r(); }
 extern "C" float *cg_solver_p(cg_solver *s, int which) { return s->impl.p(which); }
 

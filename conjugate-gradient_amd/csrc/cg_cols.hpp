@@ -48,6 +48,10 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
   Src<MODE, POL_PLAIN> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
+  // paired x update (kernel B, see CgState::xdef_k)
+  int xm = 0;
+  float alpha_prev = 0;
+  const float *__restrict__ p_prev = nullptr;
   if constexpr (MODE == MODE_A)
   {
     const IterCtl c = prologue_A(a, sh);
@@ -60,11 +64,15 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
   }
   else if constexpr (MODE == MODE_B)
   {
-    const IterCtl c = prologue_B(a, sh);
+    // (not in 5-D: kernel B there has no registers left for the second p)
+    const IterCtl c = prologue_B<(D <= 4)>(a, sh);
     if (!c.active)
       return;
     src.p = (c.k & 1) ? a.p0 : a.p1;
+    p_prev = (c.k & 1) ? a.p1 : a.p0;
     coef = c.coef;
+    xm = c.xm;
+    alpha_prev = c.alpha_prev;
   }
   else
   {
@@ -187,7 +195,7 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
       return nb;
     };
 
-    float4 pm[R], pc[R], pn[R], xv[R], rv[R];
+    float4 pm[R], pc[R], pn[R], xv[R], rv[R], qv[R];
 #pragma unroll
     for (int j = 0; j < R; j++)
     {
@@ -196,9 +204,13 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
       pn[j] = ldrow(j, y0 + 1);
       xv[j] = zero4;
       rv[j] = zero4;
+      qv[j] = zero4;
       if constexpr (MODE == MODE_B)
       {
-        xv[j] = load4<STREAM>(a.x + base + j * sb + y0 * rs);
+        if (xm != 1)
+          xv[j] = load4<STREAM>(a.x + base + j * sb + y0 * rs);
+        if (xm == 2)
+          qv[j] = load4<STREAM>(p_prev + base + j * sb + y0 * rs);
         rv[j] = load4<STREAM>(a.r + base + j * sb + y0 * rs);
       }
       if constexpr (MODE == MODE_A && GHOST)
@@ -221,18 +233,22 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
       const long long idx = base + y * rs;
       // ---- prefetch for the next rows ----------------------------------------------------
       const long long y2 = y + 2 <= y1 ? y + 2 : y1; // row y1 is the last one ever needed
-      float4 pnn[R], xn[R], rn[R];
+      float4 pnn[R], xn[R], rn[R], qn[R];
 #pragma unroll
       for (int j = 0; j < R; j++)
       {
         pnn[j] = ldrow(j, y2);
         xn[j] = zero4;
         rn[j] = zero4;
+        qn[j] = zero4;
         if constexpr (MODE == MODE_B)
         {
           if (y + 1 < y1) // wave-uniform
           {
-            xn[j] = load4<STREAM>(a.x + idx + j * sb + rs);
+            if (xm != 1)
+              xn[j] = load4<STREAM>(a.x + idx + j * sb + rs);
+            if (xm == 2)
+              qn[j] = load4<STREAM>(p_prev + idx + j * sb + rs);
             rn[j] = load4<STREAM>(a.r + idx + j * sb + rs);
           }
         }
@@ -344,6 +360,13 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
         else
         {
           float4 xo = xv[j], ro = rv[j];
+          if (xm == 2)
+          {
+            xo.x = fmaf(alpha_prev, qv[j].x, xo.x);
+            xo.y = fmaf(alpha_prev, qv[j].y, xo.y);
+            xo.z = fmaf(alpha_prev, qv[j].z, xo.z);
+            xo.w = fmaf(alpha_prev, qv[j].w, xo.w);
+          }
           xo.x = fmaf(alpha, q.x, xo.x);
           xo.y = fmaf(alpha, q.y, xo.y);
           xo.z = fmaf(alpha, q.z, xo.z);
@@ -354,7 +377,8 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
           ro.w = fmaf(-alpha, lv.w, ro.w);
           if (act)
           {
-            store4<STREAM>(a.x + ij, xo);
+            if (xm != 1)
+              store4<STREAM>(a.x + ij, xo);
             store4<STREAM>(a.r + ij, ro);
             if constexpr (GHOST)
             {
@@ -381,6 +405,7 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
         pn[j] = pnn[j];
         xv[j] = xn[j];
         rv[j] = rn[j];
+        qv[j] = qn[j];
       }
       if constexpr (SHALLOW)
         nb0 = nb2;

@@ -15,6 +15,13 @@
 // parity) because kernel A recomputes r + beta*p_old at halo points that belong to
 // other workgroups.
 //
+// Paired x update: both p buffers are intact while kernel B runs, so x need not be touched
+// every iteration.  Kernel B of an even iteration k skips x (3 words), kernel B of
+// iteration k+1 reads both p and applies x = fma(alpha_k, p_k, x), x = fma(alpha_k+1,
+// p_k+1, x) in that order (6 words): the bits of two single updates, 4.5 instead of 5
+// words per iteration on average.  Whenever the host gets control back with an update
+// pending (odd count, stop by the tolerance), a flush launch applies it (CgState::xdef_k).
+//
 // alpha, beta, the iteration counter and the stop test live on the device
 // (CgState).  Dot products are deterministic: every workgroup writes one double
 // partial; the consumer kernel's wave 0 sums the partials in a fixed order, so all
@@ -73,6 +80,13 @@ struct CgState
   float reltol;
   float alpha, beta;
   float pAp;
+  // Paired x update: kernel B of an even iteration k may leave out x += alpha_k p_k (no read, no write of x)
+  // and record xdef_k = k; kernel B of iteration k + 1 then applies both updates, in order, from the two p
+  // buffers.  A flush launch applies a pending update where the host needs x and records the iteration
+  // count it did so at.  Kernel B of iteration k reads alpha_hist[(k - 1) & 1] and writes alpha_hist[k & 1].
+  int xdef_k;       // last iteration whose x update was left out (-2: none)
+  int xflushed_at;  // iteration count at which a flush applied a pending update (-1: never)
+  float alpha_hist[2];
   float rr_hist[CG_HIST];
 };
 
@@ -97,6 +111,7 @@ struct VecArgs
   float *push_lo, *push_hi;
   const unsigned long long *push_seq;
   unsigned long long push_stride;
+  int xdefer; // kernel B may leave x alone on even iterations (see CgState::xdef_k)
 };
 
 // staging buffers of this launch: the exchange that follows kernel B is number *push_seq + 1
@@ -213,6 +228,10 @@ struct IterCtl
   bool active;
   float coef; // beta for kernel A, alpha for kernel B
   int k;
+  // kernel B, paired x update: 0 = x += alpha p as usual, 1 = leave x alone this time,
+  // 2 = x += alpha_prev p_prev first (the update iteration k - 1 left out), then x += alpha p
+  int xm;
+  float alpha_prev;
 };
 
 __device__ __forceinline__ IterCtl prologue_A(const VecArgs &a, double *sh)
@@ -240,6 +259,8 @@ __device__ __forceinline__ IterCtl prologue_A(const VecArgs &a, double *sh)
   return c;
 }
 
+// XD: this kernel implements the paired x update
+template <bool XD = false>
 __device__ __forceinline__ IterCtl prologue_B(const VecArgs &a, double *sh)
 {
   CgState *st = a.st;
@@ -249,6 +270,22 @@ __device__ __forceinline__ IterCtl prologue_B(const VecArgs &a, double *sh)
   const int done = st->doneB;
   const float pAp = (CG_DBG & 4) ? 1e9f : (float)block_read_sum(a.sumA, a.nA, sh);
   c.coef = st->rr_hist[c.k % CG_HIST] / pAp;
+  c.xm = 0;
+  c.alpha_prev = 0.0f;
+  if constexpr (XD)
+  {
+    // odd iterations only read xdef_k, even ones only write it
+    if (c.k & 1)
+    {
+      if (st->xdef_k == c.k - 1 && st->xflushed_at != c.k)
+      {
+        c.xm = 2;
+        c.alpha_prev = st->alpha_hist[0];
+      }
+    }
+    else if (a.xdefer)
+      c.xm = 1;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
     st->itA = c.active ? c.k + 1 : c.k;
@@ -257,6 +294,12 @@ __device__ __forceinline__ IterCtl prologue_B(const VecArgs &a, double *sh)
     {
       st->alpha = c.coef;
       st->pAp = pAp;
+      if constexpr (XD)
+      {
+        st->alpha_hist[c.k & 1] = c.coef;
+        if (c.xm == 1)
+          st->xdef_k = c.k;
+      }
     }
   }
   return c;
@@ -392,6 +435,10 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
   Src<MODE, POL> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
+  // paired x update (kernel B): xm and the p of the previous iteration
+  int xm = 0;
+  float alpha_prev = 0;
+  const float *__restrict__ p_prev = nullptr;
   if constexpr (MODE == MODE_A)
   {
     const IterCtl c = prologue_A(a, sh);
@@ -404,11 +451,14 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
   }
   else if constexpr (MODE == MODE_B)
   {
-    const IterCtl c = prologue_B(a, sh);
+    const IterCtl c = prologue_B<true>(a, sh);
     if (!c.active)
       return;
     src.p = (c.k & 1) ? a.p0 : a.p1;
+    p_prev = (c.k & 1) ? a.p1 : a.p0;
     coef = c.coef;
+    xm = c.xm;
+    alpha_prev = c.alpha_prev;
   }
   else
   {
@@ -523,10 +573,13 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
     float4 pn = ldrow(y0 + 1);
     float ec = ldedge(y0);
     float en = ldedge(y0 + 1 < y1 ? y0 + 1 : y0);
-    float4 xv = zero4, rv = zero4;
+    float4 xv = zero4, rv = zero4, qv = zero4;
     if constexpr (MODE == MODE_B)
     {
-      xv = load4<NT>(a.x + col0 + y0 * rs);
+      if (xm != 1)
+        xv = load4<NT>(a.x + col0 + y0 * rs);
+      if (xm == 2)
+        qv = load4<Src<MODE, POL>::NT_P>(p_prev + col0 + y0 * rs);
       rv = load4<false>(a.r + col0 + y0 * rs);
     }
     if constexpr (MODE == MODE_A)
@@ -542,12 +595,15 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
       const long long y2 = y + 2 <= y1 ? y + 2 : y1;       // row y1 is the last one ever needed
       const float4 pnn = ldrow(y2);
       const float enn = ldedge(y + 2 < y1 ? y + 2 : y1 - 1);
-      float4 xn = zero4, rn = zero4;
+      float4 xn = zero4, rn = zero4, qn = zero4;
       if constexpr (MODE == MODE_B)
       {
         if (y + 1 < y1) // wave-uniform
         {
-          xn = load4<NT>(a.x + col0 + (y + 1) * rs);
+          if (xm != 1)
+            xn = load4<NT>(a.x + col0 + (y + 1) * rs);
+          if (xm == 2)
+            qn = load4<Src<MODE, POL>::NT_P>(p_prev + col0 + (y + 1) * rs);
           rn = load4<false>(a.r + col0 + (y + 1) * rs);
         }
       }
@@ -637,6 +693,13 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
       }
       else
       {
+        if (xm == 2)
+        {
+          xv.x = fmaf(alpha_prev, qv.x, xv.x);
+          xv.y = fmaf(alpha_prev, qv.y, xv.y);
+          xv.z = fmaf(alpha_prev, qv.z, xv.z);
+          xv.w = fmaf(alpha_prev, qv.w, xv.w);
+        }
         xv.x = fmaf(alpha, pc.x, xv.x);
         xv.y = fmaf(alpha, pc.y, xv.y);
         xv.z = fmaf(alpha, pc.z, xv.z);
@@ -647,7 +710,8 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
         rv.w = fmaf(-alpha, lv.w, rv.w);
         if (act)
         {
-          store4<NT>(a.x + idx, xv);
+          if (xm != 1)
+            store4<NT>(a.x + idx, xv);
           store4<NT>(a.r + idx, rv);
           if constexpr (GHOST)
           {
@@ -683,6 +747,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
       en = enn;
       xv = xn;
       rv = rn;
+      qv = qn;
     }
     if constexpr (MODE == MODE_A)
     {

@@ -48,6 +48,10 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
   Src<MODE, POL> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
+  // paired x update (kernel B, see CgState::xdef_k)
+  int xm = 0;
+  float alpha_prev = 0;
+  const float *__restrict__ p_prev = nullptr;
   if constexpr (MODE == MODE_A)
   {
     const IterCtl c = prologue_A(a, sh);
@@ -60,11 +64,14 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
   }
   else if constexpr (MODE == MODE_B)
   {
-    const IterCtl c = prologue_B(a, sh);
+    const IterCtl c = prologue_B<true>(a, sh);
     if (!c.active)
       return;
     src.p = (c.k & 1) ? a.p0 : a.p1;
+    p_prev = (c.k & 1) ? a.p1 : a.p0;
     coef = c.coef;
+    xm = c.xm;
+    alpha_prev = c.alpha_prev;
   }
   else
   {
@@ -177,14 +184,18 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
         if (w == nw - 1)
           hd_n = ldrow(yb + R, z + dir);
       }
-      float4 xv[R], rv[R];
+      float4 xv[R], rv[R], qv[R];
       if constexpr (MODE == MODE_B)
       {
 #pragma unroll
         for (int j = 0; j < R; j++)
         {
           const long long yc = yb + j < n1 ? yb + j : n1 - 1;
-          xv[j] = load4<NT>(a.x + z * sz + yc * sy + xcl);
+          xv[j] = qv[j] = zero4;
+          if (xm != 1)
+            xv[j] = load4<NT>(a.x + z * sz + yc * sy + xcl);
+          if (xm == 2)
+            qv[j] = load4<NT>(p_prev + z * sz + yc * sy + xcl);
           rv[j] = load4<false>(a.r + z * sz + yc * sy + xcl);
         }
       }
@@ -250,6 +261,13 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
         else
         {
           float4 xo = xv[j], ro = rv[j];
+          if (xm == 2)
+          {
+            xo.x = fmaf(alpha_prev, qv[j].x, xo.x);
+            xo.y = fmaf(alpha_prev, qv[j].y, xo.y);
+            xo.z = fmaf(alpha_prev, qv[j].z, xo.z);
+            xo.w = fmaf(alpha_prev, qv[j].w, xo.w);
+          }
           xo.x = fmaf(alpha, c.x, xo.x);
           xo.y = fmaf(alpha, c.y, xo.y);
           xo.z = fmaf(alpha, c.z, xo.z);
@@ -260,7 +278,8 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
           ro.w = fmaf(-alpha, lv.w, ro.w);
           if (rowok)
           {
-            store4<NT>(a.x + idx, xo);
+            if (xm != 1)
+              store4<NT>(a.x + idx, xo);
             store4<NTS>(a.r + idx, ro);
             if constexpr (GHOST)
             {

@@ -93,8 +93,52 @@ __global__ void __launch_bounds__(64) k_init_state(CgState *st, const double *__
     st->alpha = 0;
     st->beta = 0;
     st->pAp = 0;
+    st->xdef_k = -2;
+    st->xflushed_at = -1;
+    st->alpha_hist[0] = st->alpha_hist[1] = 0;
     st->rr_hist[0] = rr;
   }
+}
+
+// Paired x update (CgState::xdef_k): applies the update the last kernel B left out, if any.  The decision
+// is read from words no workgroup of this launch writes; k_flush_mark records it afterwards.
+__global__ void __launch_bounds__(256) k_flush_x(const CgState *__restrict__ st, float *__restrict__ x,
+                                                 const float *__restrict__ p0, const float *__restrict__ p1,
+                                                 unsigned long long n, int vec4)
+{
+  const int it = st->itA;
+  if (!(it & 1) || st->xdef_k != it - 1 || st->xflushed_at == it)
+    return;
+  const float alpha = st->alpha_hist[0];
+  const float *__restrict__ p = p1; // the buffer kernel B of an even iteration reads
+  (void)p0;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec4)
+  {
+    for (unsigned long long i = t; i < n / 4; i += step)
+    {
+      float4 xv = reinterpret_cast<float4 *>(x)[i];
+      const float4 pv = reinterpret_cast<const float4 *>(p)[i];
+      xv.x = fmaf(alpha, pv.x, xv.x);
+      xv.y = fmaf(alpha, pv.y, xv.y);
+      xv.z = fmaf(alpha, pv.z, xv.z);
+      xv.w = fmaf(alpha, pv.w, xv.w);
+      reinterpret_cast<float4 *>(x)[i] = xv;
+    }
+    for (unsigned long long i = n / 4 * 4 + t; i < n; i += step)
+      x[i] = fmaf(alpha, p[i], x[i]);
+  }
+  else
+    for (unsigned long long i = t; i < n; i += step)
+      x[i] = fmaf(alpha, p[i], x[i]);
+}
+
+__global__ void __launch_bounds__(64) k_flush_mark(CgState *st)
+{
+  const int it = st->itA;
+  if (threadIdx.x == 0 && (it & 1) && st->xdef_k == it - 1)
+    st->xflushed_at = it;
 }
 
 __global__ void __launch_bounds__(64) k_set_maxit(CgState *st, int add)
@@ -513,6 +557,8 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   // hints pay at any size (16384 x 8192: +2.6 %, 16384^2: even); the rows engine in d >= 3 re-reads
   // p's far neighbours, which non-temporal loads would push back to HBM, so it uses plain accesses
   const bool keep_r = engine_ == ENGINE_PLANES || engine_ == ENGINE_MORTON4 || desc_.d <= 2;
+  // paired x update: engines whose kernel B implements it
+  xdefer_ = env_int("CG_XDEFER", 1) != 0 && ((engine_ == ENGINE_ROWS && !(rg_.sub && rg_.R && rg_.d >= 5)) || engine_ == ENGINE_PLANES);
   policy_ = env_int("CG_CACHE_POLICY", engine_ == ENGINE_PLANES ? POL_KEEP_RP : (keep_r ? POL_KEEP_R : POL_PLAIN));
   if (policy_ == POL_KEEP_RP && engine_ != ENGINE_PLANES)
     policy_ = POL_KEEP_R; // the third policy exists for the planes engine only
@@ -909,10 +955,22 @@ void Solver::launch_A()
   launch_mode(MODE_A, true, a);
 }
 
-void Solver::launch_B()
+void Solver::flush_x()
+{
+  if (!xdefer_)
+    return;
+  const int vec4 = (((uintptr_t)x_ | (uintptr_t)p1_) % 16 == 0) ? 1 : 0;
+  const int grid = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((Np_ / 4 + 255) / 256, 4096));
+  hipLaunchKernelGGL(k_flush_x, dim3(grid), dim3(256), 0, stream_, st_, x_, p0_, p1_, (unsigned long long)Np_, vec4);
+  hipLaunchKernelGGL(k_flush_mark, dim3(1), dim3(64), 0, stream_, st_);
+  CHECK(hipGetLastError());
+}
+
+void Solver::launch_B(bool may_defer)
 {
   VecArgs a = args();
   a.part_out = partB_;
+  a.xdefer = (xdefer_ && may_defer) ? 1 : 0;
   if (linked_ && push_in_b_ && (desc_.has_lo || desc_.has_hi))
   {
     // r's boundary planes travel while kernel B still runs: it stores them into the neighbours' staging
@@ -1302,6 +1360,7 @@ void Solver::iterate(int n, bool use_graph)
   {
     for (int i = 0; i < n; i++)
       launch_iteration();
+    flush_x();
     return;
   }
   // whole chunks replay one captured graph; what is left over replays a second, shorter graph, so that
@@ -1340,6 +1399,7 @@ void Solver::iterate(int n, bool use_graph)
     }
     CHECK(hipGraphLaunch(tail_graph_, stream_));
   }
+  flush_x(); // x is complete whenever the host gets control back
 }
 
 void Solver::drop_graphs()
@@ -1387,6 +1447,7 @@ void Solver::read_state(CgState *host_copy)
 
 int Solver::finish(float *residue, float *hist, int hist_len)
 {
+  flush_x();
   if (pad_ && x_user_)
     copy_rows(x_user_, desc_.extents[0], xpad_, s0_); // the read-back below waits for it
   if (relay_ && x_user_)
@@ -1436,6 +1497,7 @@ void Solver::time_kernels(int n, float *ms_A, float *ms_B)
     }
     CHECK(hipEventRecord(ev[5 * i + 4], stream_));
   }
+  flush_x();
   CHECK(hipStreamSynchronize(stream_));
   double t[4] = {0, 0, 0, 0};
   for (int i = 0; i < n; i++)

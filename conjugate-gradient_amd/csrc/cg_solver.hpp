@@ -60,6 +60,7 @@ public:
   float *p(int which) const { return which ? p1_ : p0_; }
   double *partials(int which) const { return which ? partB_ : partA_; }
   int engine() const { return engine_; }
+  bool paired_x() const { return xdefer_; }
   int blocks() const { return grid_; }
   const char *kernel_name() const;
 
@@ -84,7 +85,9 @@ public:
   void init_state(double rel, int lagged, int maxit);         // from the bound r.r sum
   void add_iterations(int n);                                 // maxit = it + n
   void launch_A();
-  void launch_B();
+  // may_defer: this launch may leave x alone (even iterations); the caller then ends with flush_x()
+  void launch_B(bool may_defer = true);
+  void flush_x();
   void launch_stencil(const float *u, float *out, bool ghost); // out = A u with this geometry
   void read_state(CgState *host_copy);                        // synchronises
 
@@ -129,6 +132,7 @@ private:
   CgState *st_host_ = nullptr;
   int engine_ = ENGINE_SCALAR;
   int policy_ = POL_KEEP_R;
+  bool xdefer_ = false; // kernel B of this solver's engine implements the paired x update
   int layout_ = LAYOUT_LEX;
   RowsGeom rg_{}, rgA_{};     // kernel B (and the plain stencil) / kernel A
   PlanesGeom pg_{}, pgA_{};

@@ -180,6 +180,10 @@ extern "C"
   /* name of the kernel template the iterations run ("k_rows", "k_cols", "k_planes", "k_morton4",
      "k_morton_tile", "k_scalar", "k_small"), as it appears in a profiler's kernel trace; static storage */
   const char *cg_solver_kernel_name(const cg_solver *s);
+  /* 1 if the iterations launched by cg_solver_iterate update x in pairs: kernel B of an even iteration
+     leaves x alone and the next one applies both updates (same bits as updating every time); such a solver
+     streams 30 instead of 32 bytes per point and iteration.  CG_XDEFER=0 turns it off. */
+  int cg_solver_paired_x(const cg_solver *s);
 
   /* whole solve, asynchronous until cg_solver_finish.  b, x: device pointers, N floats. */
   void cg_solver_begin(cg_solver *s, const float *b, float *x, double rel, int lagged);

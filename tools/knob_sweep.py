@@ -5,8 +5,8 @@
 
 Every setting is a comma-separated list of NAME=VALUE pairs applied on top of the caller's
 environment for one solver (the library reads the switches when a solver is created).  Prints mean
-microseconds of kernels A and B (HIP events, 30 iterations) and the moved-bytes rates (12 and 20 B
-per point)."""
+microseconds of kernels A and B (HIP events, 30 iterations) and the moved-bytes rates (12 B per point
+for A; 20 for B, or 18 on average when the solver updates x in pairs)."""
 import os
 import sys
 
@@ -36,7 +36,8 @@ for setting in sys.argv[2:] or [""]:
     s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
     s.iterate(5, False)
     a, bb = s.time_kernels(30)
-    name, blocks = s.kernel_name, s.blocks
+    name, blocks, bytes_b = s.kernel_name, s.blocks, 18 if s.paired_x else 20
     s.close()
     print(f"{spec:>16s} {name:>14s} grid {blocks:5d}  A {a * 1e3:8.1f} us {12 * N / a / 1e6:6.0f} GB/s   "
-          f"B {bb * 1e3:8.1f} us {20 * N / bb / 1e6:6.0f} GB/s   {1e3 / (a + bb):7.1f} it/s   [{setting}]", flush=True)
+          f"B {bb * 1e3:8.1f} us {bytes_b * N / bb / 1e6:6.0f} GB/s ({bytes_b} B/pt)   {1e3 / (a + bb):7.1f} it/s   [{setting}]",
+          flush=True)
