@@ -769,6 +769,9 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
   Src<MODE, POL_PLAIN> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
+  int xm = 0; // paired x update, as in k_rows
+  float alpha_prev = 0;
+  const float *__restrict__ p_prev = nullptr;
   if constexpr (MODE == MODE_A)
   {
     const IterCtl c = prologue_A(a, sh);
@@ -781,11 +784,14 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
   }
   else if constexpr (MODE == MODE_B)
   {
-    const IterCtl c = prologue_B(a, sh);
+    const IterCtl c = prologue_B<true>(a, sh);
     if (!c.active)
       return;
     src.p = (c.k & 1) ? a.p0 : a.p1;
+    p_prev = (c.k & 1) ? a.p1 : a.p0;
     coef = c.coef;
+    xm = c.xm;
+    alpha_prev = c.alpha_prev;
   }
   else
   {
@@ -860,9 +866,14 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
     }
     else
     {
-      const float xv = fmaf(alpha, c, a.x[i]);
       const float rv = fmaf(-alpha, lv, a.r[i]);
-      a.x[i] = xv;
+      if (xm != 1)
+      {
+        float xv = a.x[i];
+        if (xm == 2)
+          xv = fmaf(alpha_prev, p_prev[i], xv);
+        a.x[i] = fmaf(alpha, c, xv);
+      }
       a.r[i] = rv;
       if constexpr (GHOST)
       {

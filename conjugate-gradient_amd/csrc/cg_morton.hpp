@@ -33,6 +33,10 @@ __global__ void __launch_bounds__(256) k_morton4(const MortonGeom g, const VecAr
   Src<MODE, POL_PLAIN> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
+  // paired x update (kernel B, see CgState::xdef_k)
+  int xmode = 0;
+  float alpha_prev = 0;
+  const float *__restrict__ p_prev = nullptr;
   if constexpr (MODE == MODE_A)
   {
     const IterCtl c = prologue_A(a, sh);
@@ -45,11 +49,14 @@ __global__ void __launch_bounds__(256) k_morton4(const MortonGeom g, const VecAr
   }
   else if constexpr (MODE == MODE_B)
   {
-    const IterCtl c = prologue_B(a, sh);
+    const IterCtl c = prologue_B<true>(a, sh);
     if (!c.active)
       return;
     src.p = (c.k & 1) ? a.p0 : a.p1;
+    p_prev = (c.k & 1) ? a.p1 : a.p0;
     coef = c.coef;
+    xmode = c.xm;
+    alpha_prev = c.alpha_prev;
   }
   else
   {
@@ -74,10 +81,13 @@ __global__ void __launch_bounds__(256) k_morton4(const MortonGeom g, const VecAr
   {
     const unsigned i = q << 2;
     const float4 c = src.ld4((long long)i);
-    float4 xv = zero4, rv = zero4;
+    float4 xv = zero4, rv = zero4, qv = zero4;
     if constexpr (MODE == MODE_B)
     {
-      xv = load4<NT>(a.x + i);
+      if (xmode != 1)
+        xv = load4<NT>(a.x + i);
+      if (xmode == 2)
+        qv = load4<NT>(p_prev + i);
       rv = load4<false>(a.r + i);
     }
     // axis 0: elements 0,2 have bit 0 clear, elements 1,3 have it set
@@ -119,6 +129,13 @@ __global__ void __launch_bounds__(256) k_morton4(const MortonGeom g, const VecAr
     }
     else
     {
+      if (xmode == 2)
+      {
+        xv.x = fmaf(alpha_prev, qv.x, xv.x);
+        xv.y = fmaf(alpha_prev, qv.y, xv.y);
+        xv.z = fmaf(alpha_prev, qv.z, xv.z);
+        xv.w = fmaf(alpha_prev, qv.w, xv.w);
+      }
       xv.x = fmaf(alpha, c.x, xv.x);
       xv.y = fmaf(alpha, c.y, xv.y);
       xv.z = fmaf(alpha, c.z, xv.z);
@@ -127,7 +144,8 @@ __global__ void __launch_bounds__(256) k_morton4(const MortonGeom g, const VecAr
       rv.y = fmaf(-alpha, lv.y, rv.y);
       rv.z = fmaf(-alpha, lv.z, rv.z);
       rv.w = fmaf(-alpha, lv.w, rv.w);
-      store4<NT>(a.x + i, xv);
+      if (xmode != 1)
+        store4<NT>(a.x + i, xv);
       store4<false>(a.r + i, rv);
       acc = fmaf(rv.x, rv.x, acc);
       acc = fmaf(rv.y, rv.y, acc);
@@ -171,6 +189,10 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
   Src<MODE, POL_PLAIN> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
+  // paired x update (kernel B, see CgState::xdef_k)
+  int xmode = 0;
+  float alpha_prev = 0;
+  const float *__restrict__ p_prev = nullptr;
   if constexpr (MODE == MODE_A)
   {
     const IterCtl c = prologue_A(a, sh);
@@ -183,11 +205,14 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
   }
   else if constexpr (MODE == MODE_B)
   {
-    const IterCtl c = prologue_B(a, sh);
+    const IterCtl c = prologue_B<true>(a, sh);
     if (!c.active)
       return;
     src.p = (c.k & 1) ? a.p0 : a.p1;
+    p_prev = (c.k & 1) ? a.p1 : a.p0;
     coef = c.coef;
+    xmode = c.xm;
+    alpha_prev = c.alpha_prev;
   }
   else
   {
@@ -218,7 +243,7 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
   {
     const unsigned base = t << CG_MORTON_TILE_BITS;
     float4(&buf)[CG_MORTON_TILE / 4] = tile[CG_MORTON_NBUF == 2 ? par : 0];
-    float4 c[QPT], xv[QPT], rv[QPT];
+    float4 c[QPT], xv[QPT], rv[QPT], qv[QPT];
 #pragma unroll
     for (int s = 0; s < QPT; s++)
     {
@@ -227,7 +252,11 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
       c[s] = src.ld4((long long)i);
       if constexpr (MODE == MODE_B)
       {
-        xv[s] = load4<NT>(a.x + i);
+        xv[s] = qv[s] = zero4;
+        if (xmode != 1)
+          xv[s] = load4<NT>(a.x + i);
+        if (xmode == 2)
+          qv[s] = load4<NT>(p_prev + i);
         rv[s] = load4<false>(a.r + i);
       }
     }
@@ -290,6 +319,13 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
       else
       {
         float4 xo = xv[s], ro = rv[s];
+        if (xmode == 2)
+        {
+          xo.x = fmaf(alpha_prev, qv[s].x, xo.x);
+          xo.y = fmaf(alpha_prev, qv[s].y, xo.y);
+          xo.z = fmaf(alpha_prev, qv[s].z, xo.z);
+          xo.w = fmaf(alpha_prev, qv[s].w, xo.w);
+        }
         xo.x = fmaf(alpha, cc.x, xo.x);
         xo.y = fmaf(alpha, cc.y, xo.y);
         xo.z = fmaf(alpha, cc.z, xo.z);
@@ -298,7 +334,8 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
         ro.y = fmaf(-alpha, lv.y, ro.y);
         ro.z = fmaf(-alpha, lv.z, ro.z);
         ro.w = fmaf(-alpha, lv.w, ro.w);
-        store4<NT>(a.x + i, xo);
+        if (xmode != 1)
+          store4<NT>(a.x + i, xo);
         store4<false>(a.r + i, ro);
         acc = fmaf(ro.x, ro.x, acc);
         acc = fmaf(ro.y, ro.y, acc);

@@ -10,8 +10,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-# rows engine in 2-D and 1-D, padded rows, the planes engine, short rows in 3-D and 4-D (k_cols)
-GRIDS = [[1024, 1024], [1 << 20], [1002, 600], [256, 64, 64], [64, 64, 128], [64, 64, 64, 64]]
+# rows engine in 2-D and 1-D, padded rows, the planes engine, short rows in 3-D and 4-D (k_cols), the
+# one-point-per-lane engine (6-D), a grid small enough for the single-workgroup kernel (which does not pair
+# but shares the solver's flush logic)
+GRIDS = [[1024, 1024], [1 << 20], [1002, 600], [256, 64, 64], [64, 64, 128], [64, 64, 64, 64], [8] * 6, [48, 40]]
 
 
 def pair_of_solvers(lib, ext, monkeypatch, index_mode=0):
@@ -98,6 +100,34 @@ def test_both_parities_were_hit_by_the_tolerance_sweep(lib, monkeypatch):
         counts.append(s.finish()[0])
     s.close()
     assert any(c % 2 for c in counts) and any(c % 2 == 0 for c in counts), counts
+
+
+@pytest.mark.parametrize("mode,relayout", [(2, "0"), (2, "1"), (0, "1")])
+@pytest.mark.parametrize("L,d", [(64, 3), (32, 4), (128, 3)])
+def test_morton_layout(lib, monkeypatch, L, d, mode, relayout):
+    """The Z-curve kernels (CG_MORTON_RELAYOUT=0) and the internal permutation pair x updates as well."""
+    monkeypatch.setenv("CG_MORTON_RELAYOUT", relayout)
+    ext, N = [L] * d, L ** d
+    b = rhs(lib, N)
+    plain, paired = pair_of_solvers(lib, ext, monkeypatch, index_mode=mode)
+    xs = [torch.zeros(N, dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    out = []
+    for s, x in zip((plain, paired), xs):
+        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        for n in (3, 4, 20, 2):
+            s.iterate(n)
+        out.append(s.finish(hist_len=29))
+    assert out[0] == out[1] and out[0][0] == 29
+    assert torch.equal(xs[0], xs[1])
+    plain.close()
+    paired.close()
+
+
+def test_blocked_columns_in_5d_do_not_pair(lib):
+    s = lib.make_solver([32] * 5)
+    assert s.kernel_name == "k_cols" and not s.paired_x
+    s.close()
 
 
 @pytest.mark.parametrize("ext", [[1024, 1024], [256, 64, 64]])
