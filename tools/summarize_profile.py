@@ -38,13 +38,18 @@ for kind in ("fetch", "write"):
             pmc.setdefault((kind, r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
 for n in names:
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace if r["Kernel_Name"] == n]
-    full = [d for d in dur if d > 0.5 * max(dur)]           # drop the no-op launches past maxit
+    # drop no-op launches (past maxit or after a stop).  Kernel B launches of a solver that updates x in
+    # pairs alternate between two amounts of work (3 and 6 words per point): both are full work, the
+    # means below are over whole pairs
+    # (against the 90th percentile, not the maximum: a first launch can take several times as long)
+    ref = sorted(dur)[int(0.9 * (len(dur) - 1))]
+    full = [d for d in dur if 0.2 * ref < d < 3 * ref]
     k = {"calls": len(dur), "full_work_calls": len(full), "mean_us_full_work": round(statistics.mean(full) / 1e3, 3),
          "min_us": round(min(dur) / 1e3, 3)}
     for kind in ("fetch", "write"):
-        v = [x for x in pmc.get((kind, n), []) if x > 0.5 * max(pmc[(kind, n)])]
+        v = [x for x in pmc.get((kind, n), []) if x > 0.2 * max(pmc[(kind, n)])]
         if v:
-            kib = statistics.median(v)
+            kib = statistics.mean(v)
             k[f"{kind}_size_KiB_raw"] = round(kib, 1)
             k[f"{kind}_bytes"] = int(kib * 1024 * (2 if kind == "fetch" else 1))
     if "fetch_bytes" in k and "write_bytes" in k:
