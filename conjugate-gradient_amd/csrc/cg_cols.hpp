@@ -64,8 +64,7 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
   }
   else if constexpr (MODE == MODE_B)
   {
-    // (not in 5-D: kernel B there has no registers left for the second p)
-    const IterCtl c = prologue_B<(D <= 4)>(a, sh);
+    const IterCtl c = prologue_B<true>(a, sh);
     if (!c.active)
       return;
     src.p = (c.k & 1) ? a.p0 : a.p1;
@@ -85,6 +84,9 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
     push_targets(a, push_lo, push_hi);
   const float4 zero4 = make_float4(0, 0, 0, 0);
   constexpr int NA = D - 3; // column axes other than the blocked one
+  // the second p of a paired x update is fetched a row ahead like x, except in 5-D, where kernel B has no
+  // registers left for it (256 with two columns per lane) and loads it where it is used
+  constexpr bool QLATE = D >= 5;
   const long long rs = (long long)g.sy; // between consecutive rows of the march (the last axis)
   const long long sb = (long long)g.sb; // between the R columns of a lane (axis d-2)
   const long long n1 = g.n1;
@@ -209,7 +211,7 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
       {
         if (xm != 1)
           xv[j] = load4<STREAM>(a.x + base + j * sb + y0 * rs);
-        if (xm == 2)
+        if (xm == 2 && !QLATE)
           qv[j] = load4<STREAM>(p_prev + base + j * sb + y0 * rs);
         rv[j] = load4<STREAM>(a.r + base + j * sb + y0 * rs);
       }
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
           {
             if (xm != 1)
               xn[j] = load4<STREAM>(a.x + idx + j * sb + rs);
-            if (xm == 2)
+            if (xm == 2 && !QLATE)
               qn[j] = load4<STREAM>(p_prev + idx + j * sb + rs);
             rn[j] = load4<STREAM>(a.r + idx + j * sb + rs);
           }
@@ -362,10 +364,11 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
           float4 xo = xv[j], ro = rv[j];
           if (xm == 2)
           {
-            xo.x = fmaf(alpha_prev, qv[j].x, xo.x);
-            xo.y = fmaf(alpha_prev, qv[j].y, xo.y);
-            xo.z = fmaf(alpha_prev, qv[j].z, xo.z);
-            xo.w = fmaf(alpha_prev, qv[j].w, xo.w);
+            const float4 qq = QLATE ? load4<STREAM>(p_prev + ij) : qv[j];
+            xo.x = fmaf(alpha_prev, qq.x, xo.x);
+            xo.y = fmaf(alpha_prev, qq.y, xo.y);
+            xo.z = fmaf(alpha_prev, qq.z, xo.z);
+            xo.w = fmaf(alpha_prev, qq.w, xo.w);
           }
           xo.x = fmaf(alpha, q.x, xo.x);
           xo.y = fmaf(alpha, q.y, xo.y);

@@ -557,8 +557,8 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   // hints pay at any size (16384 x 8192: +2.6 %, 16384^2: even); the rows engine in d >= 3 re-reads
   // p's far neighbours, which non-temporal loads would push back to HBM, so it uses plain accesses
   const bool keep_r = engine_ == ENGINE_PLANES || engine_ == ENGINE_MORTON4 || desc_.d <= 2;
-  // paired x update: every kernel B implements it but the blocked columns in 5-D (no registers left)
-  xdefer_ = env_int("CG_XDEFER", 1) != 0 && !(engine_ == ENGINE_ROWS && rg_.sub && rg_.R && rg_.d >= 5);
+  // paired x update (every engine's kernel B implements it)
+  xdefer_ = env_int("CG_XDEFER", 1) != 0;
   policy_ = env_int("CG_CACHE_POLICY", engine_ == ENGINE_PLANES ? POL_KEEP_RP : (keep_r ? POL_KEEP_R : POL_PLAIN));
   if (policy_ == POL_KEEP_RP && engine_ != ENGINE_PLANES)
     policy_ = POL_KEEP_R; // the third policy exists for the planes engine only

@@ -10,10 +10,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-# rows engine in 2-D and 1-D, padded rows, the planes engine, short rows in 3-D and 4-D (k_cols), the
-# one-point-per-lane engine (6-D), a grid small enough for the single-workgroup kernel (which does not pair
-# but shares the solver's flush logic)
-GRIDS = [[1024, 1024], [1 << 20], [1002, 600], [256, 64, 64], [64, 64, 128], [64, 64, 64, 64], [8] * 6, [48, 40]]
+# rows engine in 2-D and 1-D, padded rows, the planes engine, short rows in 3-D, 4-D and 5-D (k_cols; in 5-D
+# the second p is loaded where it is used), the one-point-per-lane engine (6-D), a grid small enough for the
+# single-workgroup kernel (which does not pair but shares the solver's flush logic)
+GRIDS = [[1024, 1024], [1 << 20], [1002, 600], [256, 64, 64], [64, 64, 128], [64, 64, 64, 64], [32] * 5, [8] * 6,
+         [48, 40]]
 
 
 def pair_of_solvers(lib, ext, monkeypatch, index_mode=0):
@@ -122,12 +123,6 @@ def test_morton_layout(lib, monkeypatch, L, d, mode, relayout):
     assert torch.equal(xs[0], xs[1])
     plain.close()
     paired.close()
-
-
-def test_blocked_columns_in_5d_do_not_pair(lib):
-    s = lib.make_solver([32] * 5)
-    assert s.kernel_name == "k_cols" and not s.paired_x
-    s.close()
 
 
 @pytest.mark.parametrize("ext", [[1024, 1024], [256, 64, 64]])
