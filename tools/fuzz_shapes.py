@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Random grid shapes through the automatic engine choice (rows, packed rows, folded 1-D, padded
-rows, planes, single-workgroup, Morton) against the one-point-per-lane engine: 12 CG iterations,
-histories to 1e-5, solutions to 1e-5 relative L2.  usage: fuzz_shapes.py [count] [seed]
+rows, planes, single-workgroup, Morton) against the one-point-per-lane engine: 8 to 15 CG iterations in
+two calls (so that x updates left pending by the paired update get flushed mid-solve), histories to 1e-5,
+solutions to 1e-5 relative L2; and the automatic engine against itself with CG_XDEFER=0 (x updated in every
+iteration), which must agree bit for bit.  usage: fuzz_shapes.py [count] [seed]
 (FUZZ_MIN_N: smallest grid, to keep away from the launch-bound sizes that all take the scalar engine;
 FUZZ_PACKED=1: only grids of 3 to 12 dimensions whose rows have 4 to 256 points)"""
 import os
@@ -45,21 +47,28 @@ for case in range(count):
     b = torch.empty(N, dtype=torch.float32, device="cuda")
     lib.c.cg_fill_uniform(b.data_ptr(), N, 1000 + case)
     res = []
-    for engine in (2, 0):
+    iters = int(rng.integers(8, 16))
+    first = int(rng.integers(1, iters))
+    for engine, xdefer in ((2, "1"), (0, "1"), (0, "0")):
+        os.environ["CG_XDEFER"] = xdefer
         s = lib.make_solver(ext, index_mode=mode, engine=engine)
         eng = s.engine
         x = torch.zeros(N, dtype=torch.float32, device="cuda")
         s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
-        s.iterate(12, use_graph=bool(case & 1))
-        it, _, hist = s.finish(hist_len=12)
+        s.iterate(first, use_graph=bool(case & 1))
+        s.iterate(iters - first, use_graph=bool(case & 2))
+        it, _, hist = s.finish(hist_len=iters)
         s.close()
-        res.append((x.cpu().numpy().astype(np.float64), np.array(hist), it, eng))
-    (x0, h0, i0, _), (x1, h1, i1, eng) = res
+        res.append((x.cpu().numpy(), np.array(hist), it, eng))
+    same_bits = (res[1][0].view(np.uint32) == res[2][0].view(np.uint32)).all() and res[1][2] == res[2][2] and \
+        np.array_equal(res[1][1], res[2][1], equal_nan=True)
+    res = [(r[0].astype(np.float64),) + r[1:] for r in res]
+    (x0, h0, i0, _), (x1, h1, i1, eng) = res[:2]
     # a grid of a few points reaches r = 0 exactly; with the tolerance 0 used here the next step is 0/0 in
     # every engine alike (as it would be in the reference): NaNs in the same places count as agreement
     nan0, nan1 = np.isnan(x0), np.isnan(x1)
     xa, xb = np.where(nan0, 0, x0), np.where(nan1, 0, x1)
-    ok = (i0 == i1 and np.allclose(h0, h1, rtol=1e-5, equal_nan=True) and np.array_equal(nan0, nan1)
+    ok = (same_bits and i0 == i1 and np.allclose(h0, h1, rtol=1e-5, equal_nan=True) and np.array_equal(nan0, nan1)
           and np.linalg.norm(xb - xa) <= 1e-5 * max(np.linalg.norm(xa), 1e-30))
     bad += 0 if ok else 1
     print(f"{case:4d} {'x'.join(map(str, ext)):>24s} mode {mode} N={N:8d} auto->{names.get(eng, eng)} {'ok' if ok else 'MISMATCH'}",
