@@ -730,9 +730,13 @@ def main():
         else:
             # over the collectives the kernels cannot be timed in place without the all-reduces between
             # them: time the same two kernels on this rank's slab with a stand-alone solver
+            had = os.environ.get("CG_XDEFER")
             os.environ["CG_XDEFER"] = "0"     # as the step interface runs them: x updated by every kernel B
             t = lib.make_solver(ext, index_mode=mode)
-            os.environ.pop("CG_XDEFER")
+            if had is None:
+                os.environ.pop("CG_XDEFER")
+            else:
+                os.environ["CG_XDEFER"] = had
             x.zero_()
             torch.cuda.synchronize()
             t.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "hip_check.hpp"
@@ -102,16 +103,14 @@ __global__ void __launch_bounds__(64) k_init_state(CgState *st, const double *__
 
 // Paired x update (CgState::xdef_k): applies the update the last kernel B left out, if any.  The decision
 // is read from words no workgroup of this launch writes; k_flush_mark records it afterwards.
+// p: the buffer kernel B of an even iteration reads (p1); alpha_hist[0] is that iteration's alpha.
 __global__ void __launch_bounds__(256) k_flush_x(const CgState *__restrict__ st, float *__restrict__ x,
-                                                 const float *__restrict__ p0, const float *__restrict__ p1,
-                                                 unsigned long long n, int vec4)
+                                                 const float *__restrict__ p, unsigned long long n, int vec4)
 {
   const int it = st->itA;
   if (!(it & 1) || st->xdef_k != it - 1 || st->xflushed_at == it)
     return;
   const float alpha = st->alpha_hist[0];
-  const float *__restrict__ p = p1; // the buffer kernel B of an even iteration reads
-  (void)p0;
   const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
   const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (vec4)
@@ -961,7 +960,7 @@ void Solver::flush_x()
     return;
   const int vec4 = (((uintptr_t)x_ | (uintptr_t)p1_) % 16 == 0) ? 1 : 0;
   const int grid = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((Np_ / 4 + 255) / 256, 4096));
-  hipLaunchKernelGGL(k_flush_x, dim3(grid), dim3(256), 0, stream_, st_, x_, p0_, p1_, (unsigned long long)Np_, vec4);
+  hipLaunchKernelGGL(k_flush_x, dim3(grid), dim3(256), 0, stream_, st_, x_, p1_, (unsigned long long)Np_, vec4);
   hipLaunchKernelGGL(k_flush_mark, dim3(1), dim3(64), 0, stream_, st_);
   CHECK(hipGetLastError());
 }
@@ -1122,9 +1121,11 @@ void order_after_default_stream(hipStream_t s)
     return;
   constexpr int MAXDEV = 64;
   static hipEvent_t ev_of[MAXDEV] = {nullptr};
+  static std::mutex guard; // one event per device, shared by every solver: record and wait as one step
   int dev = 0;
   CHECK(hipGetDevice(&dev));
   CG_REQUIRE(dev >= 0 && dev < MAXDEV, "device ordinal out of range");
+  std::lock_guard<std::mutex> lock(guard);
   if (!ev_of[dev])
     CHECK(hipEventCreateWithFlags(&ev_of[dev], hipEventDisableTiming));
   CHECK(hipEventRecord(ev_of[dev], nullptr));
