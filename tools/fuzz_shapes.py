@@ -66,11 +66,16 @@ for case in range(count):
     (x0, h0, i0, _), (x1, h1, i1, eng) = res[:2]
     # a grid of a few points reaches r = 0 exactly; with the tolerance 0 used here the next step is 0/0 in
     # every engine alike (as it would be in the reference): NaNs in the same places count as agreement
-    nan0, nan1 = np.isnan(x0), np.isnan(x1)
+    # (or infinities, once alpha = rr / pAp has overflowed: the same ones in the same places)
+    nan0, nan1 = ~np.isfinite(x0), ~np.isfinite(x1)
     xa, xb = np.where(nan0, 0, x0), np.where(nan1, 0, x1)
     ok = (same_bits and i0 == i1 and np.allclose(h0, h1, rtol=1e-5, equal_nan=True) and np.array_equal(nan0, nan1)
+          and np.array_equal(x0[nan0], x1[nan1], equal_nan=True)
           and np.linalg.norm(xb - xa) <= 1e-5 * max(np.linalg.norm(xa), 1e-30))
     bad += 0 if ok else 1
+    if not ok:
+        print("     same_bits", bool(same_bits), "iters", i0, i1, res[2][2], "hist", h0.tolist(), h1.tolist(), res[2][1].tolist(),
+              "x", x0[:8].tolist(), x1[:8].tolist(), res[2][0][:8].tolist(), flush=True)
     print(f"{case:4d} {'x'.join(map(str, ext)):>24s} mode {mode} N={N:8d} auto->{names.get(eng, eng)} {'ok' if ok else 'MISMATCH'}",
           flush=True)
 print("mismatches:", bad)
