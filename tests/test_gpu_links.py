@@ -192,3 +192,27 @@ def test_processes_linked_through_ipc(tmp_path, lib, oracle, L, d, world):
     assert abs(int(r["iters"]) - iterse) <= max(2, 0.05 * iterse)
     assert np.all(np.abs(r["x"] - r["xt"]) < 1e-3)
     assert np.linalg.norm(r["x"] - xe) <= 1e-4 * np.linalg.norm(xe)
+
+
+def test_benchmark_with_two_ranks_on_one_gpu_as_the_launcher_starts_it(tmp_path):
+    """bench.py exactly as the multi-GPU launch runs it (torch.distributed.run, one process per rank), with
+    both ranks on this box's one GPU and gloo instead of RCCL (which refuses two ranks on a device): the
+    collectives are timed, the boxes are probed in child processes, the fastest usable transport runs the
+    timed regions, rank 0 prints one JSON line."""
+    import json
+    env = dict(os.environ, CG_BENCH_DEVICE="0")
+    for k in list(env):
+        if k.startswith("TORCHELASTIC_") or k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29683", os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "40",
+           "--warmup", "5", "--repeats", "3", "--workload", "1024x1024"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "slab2" and out["scaling"] == "weak"
+    assert out["config"]["comm"].startswith(("xgmi-links", "collectives")), out["config"]["comm"]
+    assert out["value"] > 0 and np.isfinite(out["final_residue"])
+    assert abs(out["value"] - 2 * out["iterations_per_sec_global"]) <= 1e-3 * out["value"]
