@@ -110,3 +110,38 @@ def test_neighbour_index_random_samples_at_config_sizes(lib, oracle):
             for a in (-1, 1):
                 nb = oracle.morton_neighbour(ind, d, k, a)
                 assert lib.neighbour_index_gpu(ind, k, a, L, d, N, 2) == (nb if nb < N else N)
+
+
+# ---- bench.py's byte accounting (no GPU needed) ------------------------------------------------------
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cg_bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_prices_bytes_as_documented():
+    """effective = the 44 B of the specified three-kernel fusion (A 20, B 24), whatever the kernels move;
+    moved = 32 B (A 12, B 20), or 30 B (B 18 on average) when x is updated every second iteration."""
+    bench = _bench_module()
+    N = 1 << 26
+    run = {"N": N, "msA": 0.128, "msB": 0.184, "kernel": "k_rows", "paired_x": True}
+    roof = bench.roofline_of(run, {"A": 800_000_000, "B": 1_200_000_000}, "note", {})
+    assert roof["kernel"] == "k_rows<MODE_B>" and roof["bound"] == "hbm" and roof["unit"] == "GB/s"
+    assert roof["algorithmic_bytes"] == 24 * N and roof["moved_bytes_per_point"] == 18
+    assert abs(roof["achieved"] - 24 * N / 0.184e-3 / 1e9) < 0.1
+    assert abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-4 and roof["frac"] == roof["frac_effective"]
+    assert abs(roof["achieved_moved"] - 18 * N / 0.184e-3 / 1e9) < 0.1
+    assert "effective" in roof["pricing"] and "18 B/point" in roof["pricing"]
+    assert roof["traffic"] == 1_200_000_000 and abs(roof["traffic_over_moved"] - 1.2e9 / (18 * N)) < 1e-3
+    assert abs(roof["other_kernel"]["achieved_moved"] - 12 * N / 0.128e-3 / 1e9) < 0.1
+    run["paired_x"] = False
+    assert bench.roofline_of(run)["moved_bytes_per_point"] == 20
+    its = 3000.0
+    paired, plain = bench.iteration_rates(N, its, True), bench.iteration_rates(N, its, False)
+    assert abs(paired["hbm_moved_GBps"] - 30 * N * its / 1e9) < 0.1 and abs(plain["hbm_moved_GBps"] - 32 * N * its / 1e9) < 0.1
+    assert paired["hbm_effective_GBps"] == plain["hbm_effective_GBps"]
+    assert abs(paired["hbm_frac_effective"] - 44 * N * its / 8e12) < 1e-4
