@@ -27,7 +27,7 @@ EXPORTS = [
     "cg_links_box_bytes", "cg_links_alloc", "cg_links_free", "cg_links_peer_ok", "cg_links_export", "cg_links_open",
     "cg_links_close", "cg_links_poke", "cg_links_peek", "cg_solver_bind_links", "cg_solver_exchange", "cg_solver_links_error",
     "cg_solver_links_times", "cg_noalloc_prepare", "cg_inner_product_noalloc",
-    "cg_solver_bind_partials_n", "cg_rccl_unique_id", "cg_rccl_comm_create", "cg_rccl_comm_destroy", "cg_solver_bind_rccl",
+    "cg_solver_bind_partials_n", "cg_solver_blocks_of", "cg_release_cache", "cg_rccl_unique_id", "cg_rccl_comm_create", "cg_rccl_comm_destroy", "cg_solver_bind_rccl",
 ]
 
 
@@ -117,6 +117,10 @@ class Library:
         for f in ("cg_solver_engine", "cg_solver_blocks", "cg_solver_paired_x"):
             getattr(c, f).argtypes = [vp]
             getattr(c, f).restype = i32
+        c.cg_solver_blocks_of.argtypes = [vp, i32]
+        c.cg_solver_blocks_of.restype = i32
+        c.cg_release_cache.argtypes = []
+        c.cg_release_cache.restype = None
         c.cg_solver_kernel_name.argtypes = [vp]
         c.cg_solver_kernel_name.restype = C.c_char_p
         c.cg_solver_begin.argtypes = [vp, fp, fp, C.c_double, i32]
@@ -209,6 +213,10 @@ class Library:
         self.c.laplace_gpu_jl(_ptr(ddf), _ptr(u), dx, d, L, N, index_mode, blocks, threads)
 
     # ---- additions -------------------------------------------------------------------
+    def release_cache(self):
+        """Free the solver conjugate_gradient_gpu keeps between calls."""
+        self.c.cg_release_cache()
+
     def inner_product_noalloc(self, v, w, n, result_dev, stream=None):
         """Device pointers only; (float) v.w lands in result_dev[0], asynchronously on `stream`.
         Returns the entry point's status (0 = success)."""
@@ -389,6 +397,10 @@ class Solver:
     @property
     def blocks(self):
         return self.lib.c.cg_solver_blocks(self.h)
+
+    def blocks_of(self, which):
+        """Partial sums kernel A (which = 0) / kernel B (1) writes per launch."""
+        return self.lib.c.cg_solver_blocks_of(self.h, which)
 
     @property
     def paired_x(self):

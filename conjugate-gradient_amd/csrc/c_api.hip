@@ -11,6 +11,7 @@
 
 #include <chrono>
 #include <memory>
+#include <mutex>
 
 #include "../../include/conjugate_gradient_cpu.h"
 #include "../../include/conjugate_gradient_gpu.hpp"
@@ -128,6 +129,23 @@ struct Cache
       mode = m;
     }
     return *solver;
+  }
+  // The reference allocates r, p, Ap inside the call and frees them before it returns
+  // (conjugate-gradient_gpu.cu:335-339,371-373).  A cached solver is kept between calls only while it is
+  // small (CG_CACHE_KEEP_MB, default 1024 MiB of device memory): the next call on the same grid then skips
+  // the allocations and the graph capture.  Anything larger is given back on return.
+  void release_if_large()
+  {
+    const char *e = getenv("CG_CACHE_KEEP_MB");
+    const size_t keep = (size_t)((e && *e) ? atoll(e) : 1024) << 20;
+    if (solver && solver->device_bytes() > keep)
+      release();
+  }
+  void release()
+  {
+    solver.reset();
+    L = d = 0;
+    mode = device = -1;
   }
 };
 // never destroyed: tearing HIP objects down from a static destructor at process exit is unsafe
@@ -259,8 +277,11 @@ extern "C" float conjugate_gradient_gpu_ex(const float *b, float *x, int L, int 
   sx.write_back();
   if (iters_out)
     *iters_out = n;
+  cache().release_if_large();
   return residue;
 }
+
+extern "C" void cg_release_cache(void) { cache().release(); }
 
 extern "C" float conjugate_gradient_gpu(float *b, float *x, int L, int d)
 {
@@ -356,6 +377,8 @@ int scratch_ptr(double **out)
     return (int)e;
   if (dev < 0 || dev >= NOALLOC_MAXDEV)
     return (int)hipErrorInvalidDevice;
+  static std::mutex guard; // two host threads may make their first call on a device at the same time
+  std::lock_guard<std::mutex> lock(guard);
   if (!scratch_of[dev])
   {
     double *ptr = nullptr;
@@ -511,6 +534,7 @@ extern "C" cg_solver *cg_solver_create(const cg_solver_desc *desc) { return new 
 extern "C" void cg_solver_destroy(cg_solver *s) { delete s; }
 extern "C" int cg_solver_engine(const cg_solver *s) { return s->impl.engine(); }
 extern "C" int cg_solver_blocks(const cg_solver *s) { return s->impl.blocks(); }
+extern "C" int cg_solver_blocks_of(const cg_solver *s, int which) { return s->impl.blocks_of(which); }
 extern "C" int cg_solver_paired_x(const cg_solver *s) { return s->impl.paired_x() ? 1 : 0; }
 extern "C" const char *cg_solver_kernel_name(const cg_solver *s) { return s->impl.kernel_name(); }
 

@@ -725,6 +725,19 @@ void Solver::build_geometry()
   grid_ = std::max(gridA_, gridB_);
 }
 
+size_t Solver::device_bytes() const
+{
+  size_t n = 2 * (size_t)(2 * CG_MAX_BLOCKS) * sizeof(double) + sizeof(CgState);
+  n += ((own_r_ ? 1 : 0) + (own_p0_ ? 1 : 0) + (own_p1_ ? 1 : 0)) * buflen_ * sizeof(float);
+  if (xpad_)
+    n += Np_ * sizeof(float);
+  if (sum_bufs_)
+    n += 2 * (size_t)(2 * CG_MAX_BLOCKS) * sizeof(double);
+  if (link_ctl_)
+    n += sizeof(LinkCtl);
+  return n;
+}
+
 const char *Solver::kernel_name() const
 {
   if (small_)
@@ -956,8 +969,12 @@ void Solver::launch_A()
 
 void Solver::flush_x()
 {
-  if (!xdefer_ || small_path()) // (the single-workgroup kernel updates x every iteration)
+  // nothing to do unless a kernel B that may leave x alone was enqueued since the last flush (the
+  // single-workgroup kernel and the step interface update x every iteration); the flush kernel itself
+  // decides on the device whether an update is pending
+  if (!xdefer_ || !may_be_pending_)
     return;
+  may_be_pending_ = false;
   const int vec4 = (((uintptr_t)x_ | (uintptr_t)p1_) % 16 == 0) ? 1 : 0;
   const int grid = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((Np_ / 4 + 255) / 256, 4096));
   hipLaunchKernelGGL(k_flush_x, dim3(grid), dim3(256), 0, stream_, st_, x_, p1_, (unsigned long long)Np_, vec4);
@@ -970,6 +987,8 @@ void Solver::launch_B(bool may_defer)
   VecArgs a = args();
   a.part_out = partB_;
   a.xdefer = (xdefer_ && may_defer) ? 1 : 0;
+  if (a.xdefer)
+    may_be_pending_ = true;
   if (linked_ && push_in_b_ && (desc_.has_lo || desc_.has_hi))
   {
     // r's boundary planes travel while kernel B still runs: it stores them into the neighbours' staging
@@ -1400,6 +1419,7 @@ void Solver::iterate(int n, bool use_graph)
     }
     CHECK(hipGraphLaunch(tail_graph_, stream_));
   }
+  may_be_pending_ = true; // the replayed kernels B pair their x updates
   flush_x(); // x is complete whenever the host gets control back
 }
 
@@ -1617,9 +1637,11 @@ double dot_device(const float *v, const float *w, unsigned long long n, hipStrea
   constexpr int MAXDEV = 64;
   static double *part_of[MAXDEV] = {nullptr};
   static double *host_of[MAXDEV] = {nullptr};
+  static std::mutex guard; // the scratch is shared: one call per device at a time, first use included
   int dev = 0;
   CHECK(hipGetDevice(&dev));
   CG_REQUIRE(dev >= 0 && dev < MAXDEV, "device ordinal out of range");
+  std::lock_guard<std::mutex> lock(guard);
   if (!part_of[dev])
   {
     CHECK(hipMalloc((void **)&part_of[dev], (2 * CG_MAX_BLOCKS + 1) * sizeof(double)));

@@ -62,6 +62,8 @@ public:
   int engine() const { return engine_; }
   bool paired_x() const { return xdefer_; }
   int blocks() const { return grid_; }
+  int blocks_of(int which) const { return which ? gridB_ : gridA_; } // partials kernel A (0) / kernel B (1) writes
+  size_t device_bytes() const; // device memory this solver allocated itself
   const char *kernel_name() const;
 
   // ---- whole-solve interface (all asynchronous on stream() until finish) -------------
@@ -133,6 +135,7 @@ private:
   int engine_ = ENGINE_SCALAR;
   int policy_ = POL_KEEP_R;
   bool xdefer_ = false; // kernel B of this solver's engine implements the paired x update
+  bool may_be_pending_ = false; // a kernel B that may have left x alone was enqueued since the last flush_x()
   int layout_ = LAYOUT_LEX;
   RowsGeom rg_{}, rgA_{};     // kernel B (and the plain stencil) / kernel A
   PlanesGeom pg_{}, pgA_{};

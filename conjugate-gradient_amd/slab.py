@@ -58,7 +58,8 @@ class HipSlabOps:
                                       r_buf=self.r_buf.data_ptr(), p0_buf=self.p0_buf.data_ptr(),
                                       p1_buf=self.p1_buf.data_ptr())
         self.solver.bind_partials(self.parts[0].data_ptr(), self.parts[1].data_ptr())
-        self.blocks = self.solver.blocks     # partial sums this rank's kernels write
+        self.blocks = self.solver.blocks     # partial sums this rank's kernels write (the larger of A's and B's)
+        self.blocks_of = [self.solver.blocks_of(0), self.solver.blocks_of(1)]
         self.nparts = self.blocks            # ... and the number every rank reduces
 
     def set_nparts(self, n):
@@ -87,11 +88,13 @@ class HipSlabOps:
         self.solver.begin(b.data_ptr(), x.data_ptr(), rel, lagged)
 
     def sum_tensor(self, which):
-        """The tensor whose element-wise sum over ranks the next kernel consumes.  The kernels write this
-        rank's `blocks` partial sums; the rest of a longer common array holds the previous reduction's
-        result and is cleared here, before the next in-place reduction adds it up again."""
-        if self.nparts > self.blocks:
-            self.parts[which, self.blocks:self.nparts].zero_()
+        """The tensor whose element-wise sum over ranks the next kernel consumes.  Kernel A writes this
+        rank's first blocks_of[0] entries of row 0, kernel B blocks_of[1] of row 1; the rest of the common
+        array holds the previous reduction's result and is cleared here, before the next in-place reduction
+        adds it up again."""
+        wrote = self.blocks_of[which]
+        if self.nparts > wrote:
+            self.parts[which, wrote:self.nparts].zero_()
         return self.parts[which, :self.nparts]
 
     def init_state(self, rel, lagged, maxit):

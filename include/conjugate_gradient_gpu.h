@@ -77,6 +77,12 @@ extern "C"
   float conjugate_gradient_gpu_ex(const float *b, float *x, int L, int d, int index_mode, int maxit, double rel,
                                   int lagged, int verbose, int *iters_out, float *hist, int hist_len);
 
+  /* conjugate_gradient_gpu / conjugate_gradient_gpu_ex keep their solver (r, two p buffers, the captured
+   * iteration graph) between calls on the same grid while it holds at most CG_CACHE_KEEP_MB (environment,
+   * default 1024) MiB of device memory; a larger one is freed before the call returns, as the reference
+   * frees r, Ap, p (conjugate-gradient_gpu.cu:371-373).  cg_release_cache() frees a kept solver now. */
+  void cg_release_cache(void);
+
   /* Mixed precision (conjugate-gradient_cpu.cu:334-392 with the float GPU solver as the
    * inner solve, the scheme the reference's readme.md:81 describes): outer CG in double
    * to 1e-8*|b| (cap 1000), M^-1 r by conjugate_gradient_gpu_ex(rel 1e-3, fresh-residual
@@ -176,7 +182,8 @@ extern "C"
   cg_solver *cg_solver_create(const cg_solver_desc *desc);
   void cg_solver_destroy(cg_solver *s);
   int cg_solver_engine(const cg_solver *s);
-  int cg_solver_blocks(const cg_solver *s);
+  int cg_solver_blocks(const cg_solver *s);                  /* partial sums per dot product: the larger of the two below */
+  int cg_solver_blocks_of(const cg_solver *s, int which);    /* partials kernel A (0) / kernel B (1) writes per launch */
   /* name of the kernel template the iterations run ("k_rows", "k_cols", "k_planes", "k_morton4",
      "k_morton_tile", "k_scalar", "k_small"), as it appears in a profiler's kernel trace; static storage */
   const char *cg_solver_kernel_name(const cg_solver *s);
@@ -222,7 +229,9 @@ extern "C"
   /* alternative to cg_solver_bind_partials for ranks whose solvers have different cg_solver_blocks():
    * the kernels write their own cg_solver_blocks() partials but read n addends (n = the largest
    * cg_solver_blocks() over the ranks, at most 4096), so that all ranks can all-reduce arrays of one
-   * length; the caller keeps the tail [cg_solver_blocks(), n) of its arrays zero before the reduction */
+   * length.  Kernel A writes pAp_parts[0 .. cg_solver_blocks_of(s, 0)), kernel B (and cg_solver_begin_local)
+   * rr_parts[0 .. cg_solver_blocks_of(s, 1)); the caller keeps the rest of each array, up to n, zero before
+   * every reduction (an in-place all-reduce leaves the previous sum there) */
   void cg_solver_bind_partials_n(cg_solver *s, double *pAp_parts, double *rr_parts, int n);
 
   /* --- multi-GPU on RCCL (over xGMI inside a node): the halo exchange and the two dot-product

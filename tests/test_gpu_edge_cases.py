@@ -136,3 +136,37 @@ def test_largest_grid_an_int_index_allows(lib):
     lam = 2.0 - 2.0 * np.cos(theta)
     x.mul_(lam).sub_(bf)
     assert x.abs().max().item() <= 1e-5
+
+
+def test_the_drop_in_solve_gives_its_device_memory_back(lib, monkeypatch):
+    """The reference frees r, Ap, p before conjugate_gradient_gpu returns (conjugate-gradient_gpu.cu:371-373).
+    Here a solver above CG_CACHE_KEEP_MB is freed on return, a smaller one is kept for the next call on the
+    same grid and freed by cg_release_cache()."""
+    monkeypatch.setenv("CG_GPU_QUIET", "1")
+    lib.release_cache()
+    L, d = 512, 3
+    N = L ** d
+    b = torch.rand(N, dtype=torch.float32, device="cuda")
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    lib.conjugate_gradient_gpu_ex(b.data_ptr(), x.data_ptr(), L, d, maxit=4)      # 3 x 513 MiB: above the limit
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free0 - free1) <= 64 << 20, (free0, free1)
+    assert float(x.abs().max()) > 0
+    del b, x
+    # a small grid stays cached (the second call reuses it) until it is released
+    L, d = 256, 2
+    N = L ** d
+    b = torch.rand(N, dtype=torch.float32, device="cuda")
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    r1 = lib.conjugate_gradient_gpu_ex(b.data_ptr(), x.data_ptr(), L, d, maxit=10)
+    x.zero_()
+    r2 = lib.conjugate_gradient_gpu_ex(b.data_ptr(), x.data_ptr(), L, d, maxit=10)
+    assert r1 == r2
+    monkeypatch.setenv("CG_CACHE_KEEP_MB", "0")
+    x.zero_()
+    r3 = lib.conjugate_gradient_gpu_ex(b.data_ptr(), x.data_ptr(), L, d, maxit=10)  # limit 0: freed on return
+    assert r3 == r1
+    lib.release_cache()                                                             # nothing left: a no-op
+    lib.release_cache()

@@ -170,3 +170,27 @@ def test_second_solve_on_the_same_solver(lib, monkeypatch):
         assert torch.equal(xs[0], xs[1])
     plain.close()
     paired.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 4])
+def test_kernel_timing_on_a_single_workgroup_grid_keeps_x_complete(lib, monkeypatch, n):
+    """cg_solver_time_kernels launches kernels A and B (which pair x updates) even on a grid whose
+    cg_solver_iterate runs the single-workgroup kernel (which updates x every iteration): an update left
+    pending by the last timed kernel B must be flushed, and later iterations must continue from a complete x."""
+    ext, N = [48, 40], 48 * 40
+    b = rhs(lib, N)
+    plain, paired = pair_of_solvers(lib, ext, monkeypatch)
+    assert paired.kernel_name == "k_small"
+    xs = [torch.zeros(N, dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    plain.begin(b.data_ptr(), xs[0].data_ptr(), 0.0, 1)
+    plain.iterate(n + 5)
+    paired.begin(b.data_ptr(), xs[1].data_ptr(), 0.0, 1)
+    paired.time_kernels(n)
+    paired.sync()
+    paired.iterate(5)
+    out = [s.finish(hist_len=n + 5) for s in (plain, paired)]
+    assert out[0] == out[1] and out[0][0] == n + 5
+    assert torch.equal(xs[0], xs[1])
+    plain.close()
+    paired.close()

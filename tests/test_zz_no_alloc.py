@@ -17,7 +17,7 @@ def _as_bits(v):
 def test_noalloc_inner_product_matches_inner_product_gpu(lib):
     assert lib.c.cg_noalloc_prepare() == 0
     g = torch.Generator(device="cuda").manual_seed(7)
-    n1, n2 = (1 << 22) + 13, 70001   # 4097 and 70 workgroups: the second call leaves most old partials behind
+    n1, n2 = (1 << 22) + 13, 70001   # 2048 (the launch cap) and 70 workgroups: the second call leaves most old partials behind
     v = torch.rand(n1, device="cuda", generator=g) - 0.5
     w = torch.rand(n1, device="cuda", generator=g) - 0.5
     out = torch.full((2,), float("nan"), device="cuda")
