@@ -2,34 +2,42 @@
 """Benchmark of the fused Laplace-CG iteration on MI355X.
 
     python bench.py --gpus 1 --steps 200 --warmup 10
+    python bench.py --gpus N ...            (starts N rank processes itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one CG iteration (kernel A + kernel B) over the whole grid.  Workload at every N:
 each GPU owns an 8192 x 8192 float slab (2^26 points, config "2D Laplace 8192^2 float CG");
 with N > 1 the slabs stack along axis 1 into an 8192 x (8192 N) grid (weak scaling) with one
 halo row of r each way and two dot-product exchanges per iteration (config.comm says which
-transport ran).  Synthetic data: b = u01 (counter-based generator, seed 1234), x0 = 0; float CG
-cannot converge on this grid within any practical count, so every step does full work (the stop
-tolerance is set to 0).
+transport ran).  A multi-rank run also measures, in the same process group and with the same
+transport, config "3D Laplace 1024^3 slab-decomposed over 8 GPUs" as weak scaling of its
+per-GPU slab (1024 x 1024 x 128 on every GPU: exactly that configuration at N = 8) and reports
+it as the object `config3`; both carry `single_gpu_reference`, the same slab solved on one GPU
+without any exchange in the same run.  Synthetic data: b = u01 (counter-based generator, seed
+1234 + rank), x0 = 0; float CG cannot converge on these grids within any practical count, so
+every step does full work (the stop tolerance is set to 0).
 
 Timing: after the warm-up the region "exactly --steps iterations between barrier + synchronize"
 is timed --repeats times in a row on the same running solve (every iteration does full work);
 value and ms_per_step are the MEDIAN region, min and max are printed beside it.
 
-Bytes.  Three prices per grid point, always named:
-  effective  the three-kernel fusion the hot path is specified with: A 20 B (stencil + dot 8, p
-             update 12), B 24 B, iteration 44 B.  roofline.achieved / roofline.frac use this price,
-             so they can exceed the HBM peak: this design never stores A p and reads p once less.
-  moved      what these kernels really stream: A 12 B (r, p_old in, p_new out), B 20 B (x, p, r in,
-             x, r out), iteration 32 B.  With the paired x update (config.paired_x_update: kernel B of
-             an even iteration leaves x alone, the next one reads both p and applies both updates) a
-             pair of B launches moves 12 + 24 B: B 18 B on average, iteration 30 B.  frac_moved is the
-             bandwidth the memory system delivers -- at 8192^2 part of it from the 256 MiB Infinity
-             Cache, which holds r.
-  counter    bytes leaving L2 per launch, measured in this run by two rocprofv3 --pmc passes
-             (FETCH_SIZE doubled as the gfx950 counter reports half of wide reads, WRITE_SIZE as is);
-             Infinity-Cache hits are included, so it bounds HBM traffic from above.  null when the
-             counter passes could not run.
+Bytes per grid point, always named:
+  moved      what these kernels stream, the algorithmic traffic of this two-kernel design: A 12 B
+             (r, p_old in, p_new out), B 20 B (x, p, r in, x, r out), iteration 32 B.  With the
+             paired x update (config.paired_x_update: kernel B of an even iteration leaves x alone,
+             the next one reads both p and applies both updates) a pair of B launches moves
+             12 + 24 B: B 18 B on average, iteration 30 B.  roofline.achieved / roofline.frac and
+             hbm_frac_moved use this price: bandwidth the memory system delivers -- at 8192^2 part
+             of it from the 256 MiB Infinity Cache, which holds r; `roofline_hbm_bound` repeats the
+             measurement on a grid whose vectors are twice that cache.
+  counter    bytes leaving L2 per launch (roofline.traffic), measured in this run by two rocprofv3
+             --pmc passes (FETCH_SIZE doubled as the gfx950 counter reports half of wide reads,
+             WRITE_SIZE as is); Infinity-Cache hits are included, so it bounds HBM traffic from
+             above.  null when the counter passes could not run.
+  three-kernel equivalent   the 44 B (A 20, B 24) of the textbook fusion that stores A p (stencil +
+             dot, x/r update + dot, p update).  Not a bandwidth: this design never moves those bytes.
+             Reported only as `three_kernel_equivalent_GBps`, the rate such a solver would need for
+             the same iterations/s.
 cpu_baseline: one CG iteration's worth of the reference's own CPU calls (fp64, one core) on the
 full workload grid where that takes under a minute, else on a bounded cubic sample.
 """
@@ -48,16 +56,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
-# bytes per grid point: "effective" = the specified three-kernel fusion, "moved" = what this design streams
-BYTES = {"A": {"effective": 20, "moved": 12}, "B": {"effective": 24, "moved": 20},
-         "iter": {"effective": 44, "moved": 32}}
+# bytes per grid point: "moved" = what this design streams (its algorithmic traffic), "equivalent" = the
+# three-kernel fusion that stores A p (only ever reported as an equivalent rate, never as a fraction)
+BYTES = {"A": {"equivalent": 20, "moved": 12}, "B": {"equivalent": 24, "moved": 20},
+         "iter": {"equivalent": 44, "moved": 32}}
 # a solver that updates x every second iteration (two updates at once): B moves 12 and 24 B in turn
-BYTES_PAIRED = {"A": BYTES["A"], "B": {"effective": 24, "moved": 18}, "iter": {"effective": 44, "moved": 30}}
+BYTES_PAIRED = {"A": BYTES["A"], "B": {"equivalent": 24, "moved": 18}, "iter": {"equivalent": 44, "moved": 30}}
 
 
 def bytes_of(paired):
     return BYTES_PAIRED if paired else BYTES
+
+
 BEYOND_CACHE_WORKLOAD = "16384x8192"   # 2^27 points: every vector is twice the Infinity Cache
+CONFIG3_SLAB = "3d-1024x128"           # one GPU's share of the 1024^3 grid cut into 8 slabs
 
 
 def parse():
@@ -73,10 +85,14 @@ def parse():
                     help="weak: every GPU owns a --workload grid; strong: the --workload grid is cut into --gpus slabs")
     ap.add_argument("--comm", default="auto", help="multi-rank exchange: auto (the fastest of the library's RCCL calls, "
                     "the direct xGMI boxes and the Python-driven collectives that passes a self-check) | rccl | links | collectives")
+    ap.add_argument("--probe-seconds", type=float, default=60.0,
+                    help="time limit for all sandboxed transport probes together; what has not answered by then is not used")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="multi-rank runs: skip the second workload (1024 x 1024 x 128 per GPU, the 8-GPU configuration's slab)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps iterations; the median is reported")
-    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--no-beyond-cache", action="store_true",
                     help="skip the second, larger 2-D workload whose vectors exceed the Infinity Cache")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -215,7 +231,8 @@ def run_single(lib, ext, mode, steps, warmup, repeats, graph, barrier, device):
 
 
 def roofline_of(run, traffic=None, traffic_note=None, traffic_detail=None):
-    """The roofline object of the dominant kernel of one run_single() result."""
+    """The roofline object of the dominant kernel of one run_single() result.  achieved = the bytes the
+    kernel streams per launch (moved price x points) / its mean launch time; frac = achieved / HBM peak."""
     N, msA, msB = run["N"], run["msA"], run["msB"]
     dom, other = ("B", "A") if msB >= msA else ("A", "B")
     ms = {"A": msA, "B": msB}
@@ -224,26 +241,27 @@ def roofline_of(run, traffic=None, traffic_note=None, traffic_detail=None):
     def rate(k, price):
         return BYTES[k][price] * N / (ms[k] * 1e-3) / 1e9
 
-    eff, mov = rate(dom, "effective"), rate(dom, "moved")
+    mov = rate(dom, "moved")
     roof = {"bound": "hbm", "kernel": run["kernel"] + f"<MODE_{dom}>",
-            "achieved": round(eff, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(eff / HBM_PEAK_GBPS, 4),
-            "pricing": f"effective: {BYTES[dom]['effective']} B/point of the specified three-kernel fusion; this kernel "
-                       f"streams {BYTES[dom]['moved']} B/point (see frac_moved), so the effective figure can exceed the peak",
-            "frac_effective": round(eff / HBM_PEAK_GBPS, 4),
-            "achieved_moved": round(mov, 1), "frac_moved": round(mov / HBM_PEAK_GBPS, 4),
-            "moved_bytes_per_point": BYTES[dom]["moved"],
+            "achieved": round(mov, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(mov / HBM_PEAK_GBPS, 4),
+            "pricing": f"moved: the {BYTES[dom]['moved']} B/point this kernel streams per launch"
+                       + (" (x is updated every second iteration: launches of 12 and 24 B/point alternate)"
+                          if dom == "B" and run.get("paired_x") else ""),
+            "algorithmic_bytes": BYTES[dom]["moved"] * N, "algorithmic_bytes_per_point": BYTES[dom]["moved"],
+            "ms_per_launch": round(ms[dom], 5),
             "traffic": (traffic or {}).get(dom), "traffic_note": traffic_note,
-            "algorithmic_bytes": BYTES[dom]["effective"] * N,
-            "algorithmic_bytes_per_point": BYTES[dom]["effective"], "ms_per_launch": round(ms[dom], 5),
+            "three_kernel_equivalent_GBps": round(rate(dom, "equivalent"), 1),
             "other_kernel": {"kernel": f"MODE_{other}", "ms_per_launch": round(ms[other], 5),
-                             "achieved_effective": round(rate(other, "effective"), 1),
-                             "achieved_moved": round(rate(other, "moved"), 1),
-                             "frac_moved": round(rate(other, "moved") / HBM_PEAK_GBPS, 4),
+                             "algorithmic_bytes_per_point": BYTES[other]["moved"],
+                             "achieved": round(rate(other, "moved"), 1),
+                             "frac": round(rate(other, "moved") / HBM_PEAK_GBPS, 4),
                              "traffic": (traffic or {}).get(other)}}
     if traffic and dom in traffic:
         roof["achieved_counter"] = round(traffic[dom] / (ms[dom] * 1e-3) / 1e9, 1)
         roof["frac_counter"] = round(roof["achieved_counter"] / HBM_PEAK_GBPS, 4)
-        roof["traffic_over_moved"] = round(traffic[dom] / (BYTES[dom]["moved"] * N), 4)
+        roof["traffic_over_algorithmic"] = round(traffic[dom] / (BYTES[dom]["moved"] * N), 4)
+    if traffic and other in traffic:
+        roof["other_kernel"]["traffic_over_algorithmic"] = round(traffic[other] / (BYTES[other]["moved"] * N), 4)
     if traffic_detail:
         roof["traffic_detail"] = traffic_detail
     return roof
@@ -308,12 +326,12 @@ def run_mixed(args, lib, device):
 
 
 def iteration_rates(N, its, paired=False):
-    """Whole-iteration byte rates of `its` iterations/s on N points, both prices."""
+    """Whole-iteration byte rates of `its` iterations/s on N points."""
     BYTES = bytes_of(paired)
-    eff = BYTES["iter"]["effective"] * N * its / 1e9
     mov = BYTES["iter"]["moved"] * N * its / 1e9
-    return {"hbm_effective_GBps": round(eff, 1), "hbm_frac_effective": round(eff / HBM_PEAK_GBPS, 4),
-            "hbm_moved_GBps": round(mov, 1), "hbm_frac_moved": round(mov / HBM_PEAK_GBPS, 4)}
+    return {"hbm_moved_GBps": round(mov, 1), "hbm_frac_moved": round(mov / HBM_PEAK_GBPS, 4),
+            "moved_bytes_per_point_per_iteration": BYTES["iter"]["moved"],
+            "three_kernel_equivalent_GBps": round(BYTES["iter"]["equivalent"] * N * its / 1e9, 1)}
 
 
 def cpu_baseline_c1():
@@ -536,10 +554,10 @@ def probe_child(args):
     dist.destroy_process_group()
 
 
-def probe_in_sandbox(name, args, port_offset):
+def probe_in_sandbox(name, args, port_offset, timeout_s=60.0):
     """Run probe_child(name) as a child process of this rank (every rank does; the children form their own
     process group on MASTER_PORT + port_offset).  Returns (ok, seconds, why) of THIS rank's child; a child
-    that crashes, hangs (killed after 120 s) or prints nothing counts as not ok."""
+    that crashes, hangs (killed after timeout_s) or prints nothing counts as not ok."""
     env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset))
     # under torch.distributed.run the ranks are told to use the launcher's store on MASTER_PORT; the children
     # rendezvous on a port of their own, so their rank 0 has to host the store itself
@@ -548,7 +566,7 @@ def probe_in_sandbox(name, args, port_offset):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--probe-child", name, "--workload", args.workload,
            "--scaling", args.scaling, "--backend", args.backend, "--gpus", str(args.gpus)]
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
         for line in reversed(r.stdout.splitlines()):
             if line.startswith("PROBE_RESULT "):
                 out = json.loads(line[len("PROBE_RESULT "):])
@@ -560,8 +578,323 @@ def probe_in_sandbox(name, args, port_offset):
         return False, None, repr(e)[:200]
 
 
+def begin_finish_ms(lib, ext, mode, device):
+    """Milliseconds of cg_solver_begin + cg_solver_finish with no iteration between them: what a solve costs
+    beyond its iterations (r = b, p = 0, |b|; for a Morton grid kept in lexicographic order inside the solver
+    also the three permutation passes: b and x in, x out).  Median of three after one untimed round."""
+    import torch
+    N = 1
+    for e in ext:
+        N *= e
+    b = torch.empty(N, dtype=torch.float32, device=device)
+    x = torch.zeros(N, dtype=torch.float32, device=device)
+    lib.c.cg_fill_uniform(C.c_void_p(b.data_ptr()), N, 1234)
+    s = lib.make_solver(ext, index_mode=mode)
+    ts = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.finish()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    s.close()
+    return statistics.median(ts[1:])
+
+
+def morton_both_ways(args, lib, ext, mode, run, barrier, device):
+    """A Morton-ordered grid is solved in lexicographic order inside the solver (b, x permuted in at begin, x
+    permuted back at finish) because those kernels move fewer bytes per iteration.  Report both: the rate of
+    a whole 200-iteration solve (the reference's cap, conjugate-gradient_gpu.cu:348) with the permutations
+    included, and the kernels that work on the Z-curve directly (CG_MORTON_RELAYOUT=0)."""
+    cap = 200
+    its = args.steps / statistics.median(run["times"])
+    over = begin_finish_ms(lib, ext, mode, device)
+    had = os.environ.get("CG_MORTON_RELAYOUT")
+    os.environ["CG_MORTON_RELAYOUT"] = "0"
+    try:
+        over_n = begin_finish_ms(lib, ext, mode, device)
+        run_n = run_single(lib, ext, mode, args.steps, args.warmup, max(3, args.repeats // 2 + 1), not args.no_graph, barrier, device)
+    finally:
+        if had is None:
+            os.environ.pop("CG_MORTON_RELAYOUT")
+        else:
+            os.environ["CG_MORTON_RELAYOUT"] = had
+    its_n = args.steps / statistics.median(run_n["times"])
+
+    def solve_rate(rate, over_ms):
+        return cap / (cap / rate + over_ms * 1e-3)
+
+    return {"morton": {
+        "ran": f"lexicographic order inside the solver ({run['kernel']}); b and x are permuted at begin, x back at finish",
+        "hot_loop_iterations_per_sec": round(its, 3), "begin_finish_ms": round(over, 4),
+        "iterations_per_sec_of_a_200_iteration_solve": round(solve_rate(its, over), 3),
+        "native": dict({"ran": f"the Z-curve kernels ({run_n['kernel']}, CG_MORTON_RELAYOUT=0)",
+                        "hot_loop_iterations_per_sec": round(its_n, 3), "begin_finish_ms": round(over_n, 4),
+                        "iterations_per_sec_of_a_200_iteration_solve": round(solve_rate(its_n, over_n), 3),
+                        "ms_per_step": round(1e3 / its_n, 5),
+                        "roofline": roofline_of(run_n, None, "not collected for this run")},
+                       **iteration_rates(run_n["N"], its_n, run_n["paired_x"]))}}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes here (fresh interpreters
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU), before this process has made any GPU
+    call, pass rank 0's output through, and exit non-zero if any rank does."""
+    import socket
+    import threading
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), CG_BENCH_SPAWNED="1")
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+            del env[k]
+        # rank 0 prints the result line; whatever the other ranks print is diagnostics
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    rc = 0
+    left = set(range(n))
+    while left:
+        for r in sorted(left):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            left.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                print(f"bench.py: rank {r} exited with {c}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in left:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    t.join(timeout=5)
+    return rc
+
+
+def pick_transport(args, s, b, x, barrier, rank, world):
+    """Which exchange carries the multi-rank run: the library's own RCCL calls (graph-captured), the direct
+    xGMI boxes, or the Python-driven collectives.  A candidate is used only if it could be set up on every
+    rank, reproduced the collectives' residual history, delivered ghost planes that equal the neighbours'
+    boundary planes bit for bit, and (with --comm auto) was the fastest in a 30-iteration probe.  The
+    candidates are tried in child processes first (probe_in_sandbox): a transport that aborts or hangs on
+    this machine must not take the benchmark down with it; all probes together get --probe-seconds.
+    Returns (pick, note, probes)."""
+    import torch.distributed as dist
+    candidates = {"auto": ["rccl", "links"], "rccl": ["rccl"], "links": ["links"], "collectives": []}[args.comm]
+    if args.backend != "nccl" and world > 1:
+        candidates = [c for c in candidates if c != "rccl"]   # rehearsal backends share one GPU: RCCL refuses that
+    probes, notes = {}, []
+    if not candidates:
+        return "collectives", "", probes
+    t_coll, hist_c, err_c = slab_probe(s, b, x, barrier, rank, world)
+    if err_c:
+        raise SystemExit(f"probe over the collectives failed: {err_c}")
+    probes["collectives"] = t_coll
+    deadline = time.monotonic() + args.probe_seconds
+    for k, name in enumerate(candidates):
+        if args.no_sandbox:
+            ok, t_new, why = check_candidate(s, name, hist_c, b, x, barrier, rank, world)
+        else:
+            # every rank allows its child the same time: rank 0's clock decides
+            left = [deadline - time.monotonic()]
+            if world > 1:
+                dist.broadcast_object_list(left, src=0)
+            if left[0] < 8.0:
+                notes.append(f"{name}: not probed (the --probe-seconds budget was used up)")
+                continue
+            ok, t_new, why = probe_in_sandbox(name, args, 101 + 7 * k, left[0])
+            seen = [None] * world
+            if world > 1:
+                dist.all_gather_object(seen, (ok, t_new, why))
+            else:
+                seen = [(ok, t_new, why)]
+            ok = all(o for o, _, _ in seen)
+            t_new = max((t for _, t, _ in seen if t is not None), default=None)
+            why = "; ".join(sorted({w for o, _, w in seen if not o and w}))
+        if ok and t_new is not None:
+            probes[name] = t_new
+        else:
+            notes.append(f"{name}: {why}")
+    usable = [c for c in candidates if c in probes]
+    if args.comm == "auto":
+        pick = min(["collectives"] + usable, key=lambda c: probes[c])
+    elif usable:
+        pick = usable[0]
+    else:
+        raise SystemExit(f"--comm {args.comm} unavailable: {'; '.join(notes)}")
+    note = "probe seconds for 30 iterations: " + ", ".join(f"{k} {v:.4f}" for k, v in probes.items())
+    if notes:
+        note += "; " + "; ".join(notes)
+    return pick, note, probes
+
+
+COMM_NAMES = {"rccl": "rccl-in-library", "links": "xgmi-links", "collectives": "collectives"}
+
+
+def run_slab(args, lib, ext, mode, rank, world, device, barrier, pick=None):
+    """One multi-rank workload: every rank owns an `ext` slab.  pick: the transport to use (None: choose it,
+    see pick_transport).  Returns a dict with the median-region time (max over ranks), the transport that
+    ran, the roofline of rank 0's dominant kernel and the single-GPU reference of the same slab."""
+    import torch
+    import torch.distributed as dist
+    from conjugate_gradient_amd.slab import SlabCG
+    N = 1
+    for e in ext:
+        N *= e
+    b = torch.empty(N, dtype=torch.float32, device=device)
+    x = torch.zeros(N, dtype=torch.float32, device=device)
+    lib.c.cg_fill_uniform(C.c_void_p(b.data_ptr()), N, 1234 + rank)   # rank-distinct synthetic right-hand side
+    torch.cuda.synchronize()
+    s = SlabCG(lib, ext, rank=rank, world=world, device=device)
+    note = ""
+    if pick is None:
+        pick, note, _ = pick_transport(args, s, b, x, barrier, rank, world)
+    if pick == "rccl" and not s.enable_rccl():
+        pick, note = "collectives", note + f"; rccl could not be set up in the benchmark process: {s.rccl_reason}"
+    if pick == "links" and not s.enable_links():
+        pick, note = "collectives", note + f"; links could not be set up in the benchmark process: {s.links_reason}"
+    comm = COMM_NAMES[pick]
+    x.zero_()
+
+    def timed():
+        x.zero_()
+        barrier()
+        s.begin(b, x, 0.0, 1)
+        s.iterate(args.warmup)
+        s.sync()
+        ts = []
+        for _ in range(args.repeats):
+            barrier()
+            t0 = time.perf_counter()
+            s.iterate(args.steps)
+            s.sync()
+            barrier()
+            ts.append(time.perf_counter() - t0)
+        done, res, _ = s.finish()
+        if done != args.warmup + args.steps * args.repeats:
+            raise RuntimeError(f"{done} iterations ran instead of {args.warmup + args.steps * args.repeats}")
+        return ts, res
+
+    ok = 1
+    try:
+        times, res = timed()
+    except RuntimeError as e:
+        if comm == "collectives":
+            raise
+        ok, note = 0, note + f"; timed run over {comm} failed: " + str(e)
+    if comm != "collectives" and not s._all_agree(ok):
+        # a rank lost the fast path under load: everyone goes back to the collectives
+        s.disable_links()
+        s.disable_rccl()
+        comm, pick = "collectives", "collectives"
+        times, res = timed()
+    rccl_ranks = s.ops.solver.rccl_ranks() if comm == "rccl-in-library" else None
+    nk = max(10, min(50, args.steps)) // 2 * 2      # whole pairs of the paired x update
+    if comm != "collectives":
+        with s._ctx():
+            msA, msB = s.ops.solver.time_kernels(nk)
+            s.sync()
+        xA, xB = s.ops.solver.links_times()
+        exchange = {"after_A": round(xA, 5), "after_B": round(xB, 5)}
+    else:
+        # over the collectives the kernels cannot be timed in place without the all-reduces between
+        # them: time the same two kernels on this rank's slab with a stand-alone solver
+        had = os.environ.get("CG_XDEFER")
+        os.environ["CG_XDEFER"] = "0"     # as the step interface runs them: x updated by every kernel B
+        t = lib.make_solver(ext, index_mode=mode)
+        if had is None:
+            os.environ.pop("CG_XDEFER")
+        else:
+            os.environ["CG_XDEFER"] = had
+        x.zero_()
+        torch.cuda.synchronize()
+        t.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        t.iterate(5, use_graph=False)
+        msA, msB = t.time_kernels(nk)
+        t.close()
+        exchange = None
+    # the step interface the Python-driven collectives use updates x in every kernel B
+    paired = s.ops.solver.paired_x and comm != "collectives"
+    roof = roofline_of({"N": N, "msA": msA, "msB": msB, "kernel": s.ops.solver.kernel_name, "paired_x": paired},
+                       None, "not collected in multi-rank runs")
+    roof["exchange_ms"] = exchange
+    roof["rank"] = 0
+    if comm == "rccl-in-library":
+        s.disable_rccl()
+    elif comm == "xgmi-links":
+        s.disable_links()
+    s.ops.solver.close()
+    del s
+    # the same slab on one GPU with nothing to exchange, in the same run: what N ranks would each do alone
+    barrier()
+    x.zero_()
+    solo = lib.make_solver(ext, index_mode=mode)
+    solo.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+    solo.iterate(args.warmup, use_graph=not args.no_graph)
+    solo.sync()
+    ts1 = []
+    for _ in range(max(3, args.repeats // 2 + 1)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solo.iterate(args.steps, use_graph=not args.no_graph)
+        solo.sync()
+        ts1.append(time.perf_counter() - t0)
+    solo.finish()
+    solo.close()
+    del b, x
+    both = torch.tensor(times + [statistics.median(ts1)], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)      # every region's time is the maximum over ranks
+    both = [float(v) for v in both.tolist()]
+    return {"N": N, "times": both[:-1], "solo_seconds": both[-1], "res": res, "comm": comm, "pick": pick, "note": note.strip("; "),
+            "roof": roof, "paired": bool(paired), "rccl_ranks": rccl_ranks}
+
+
+def slab_line(args, ext, mode, workload, world, r):
+    """The result fields of one run_slab() outcome."""
+    N, times = r["N"], r["times"]
+    dt = statistics.median(times)
+    its = args.steps / dt
+    solo = args.steps / r["solo_seconds"]
+    weak = args.scaling == "weak"
+    out = {"metric": "cg_iterations_per_sec", "value": round(its * (world if weak else 1), 3),
+           "unit": ("CG iterations/s of the whole grid (strong scaling)" if not weak else
+                    "CG iterations/s per 2^%d-point slab, summed over GPUs" % (N.bit_length() - 1)
+                    if (N & (N - 1)) == 0 else "CG iterations/s per slab, summed over GPUs"),
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": args.scaling,
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": workload, "local_extents": ext, "global_extents": ext[:-1] + [ext[-1] * world],
+                      "index_mode": mode, "points_per_gpu": N, "parallelism": f"slab{world}", "graph": True,
+                      "backend": args.backend, "comm": r["comm"] + (f" ({r['note']})" if r["note"] else ""),
+                      "rccl_ranks": r["rccl_ranks"], "paired_x_update": r["paired"], "rhs": "u01 seed 1234+rank", "x0": 0},
+           "timing": {"regions": args.repeats, "statistic": "median, every region the maximum over ranks",
+                      "ms_per_step_min_max": [round(min(times) / args.steps * 1e3, 5), round(max(times) / args.steps * 1e3, 5)],
+                      "ms_per_step_all": [round(t / args.steps * 1e3, 5) for t in times]},
+           "iterations_per_sec_global": round(its, 3),
+           "single_gpu_reference": {"value": round(solo, 3), "ms_per_step": round(r["solo_seconds"] / args.steps * 1e3, 5),
+                                    "note": "the same slab on one GPU with no neighbours and no exchange, timed in this run "
+                                            "after the multi-rank regions (median region, maximum over ranks)"},
+           "final_residue": r["res"]}
+    out.update(iteration_rates(N * world, its, r["paired"]))   # all ranks' points move once per global iteration
+    out["roofline"] = r["roof"]
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_package
@@ -571,8 +904,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "CG_BENCH_DEVICE" in os.environ:  # rehearsal on a one-GPU box: every rank on the same device
         local_rank = int(os.environ["CG_BENCH_DEVICE"])
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank process per GPU is needed "
+                         "(plain `python bench.py --gpus N` starts them itself; so does torch.distributed.run)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or args.force_slab:
@@ -595,197 +931,73 @@ def main():
         if ext[-1] % world:
             raise SystemExit(f"the slowest axis ({ext[-1]}) must be divisible by --gpus {world}")
         ext = ext[:-1] + [ext[-1] // world]
-    N = 1
-    for e in ext:
-        N *= e
 
     def barrier():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
-    roof = None
-    extra = {}
-    single = world == 1 and not args.force_slab
-    if single:
-        run = run_single(lib, ext, mode, args.steps, args.warmup, args.repeats, not args.no_graph, barrier, device)
-        times, res = run["times"], run["residue"]
+    graph = not args.no_graph
+    if world == 1 and not args.force_slab:
+        run = run_single(lib, ext, mode, args.steps, args.warmup, args.repeats, graph, barrier, device)
+        N, times = run["N"], run["times"]
         traffic, tnote, tdetail = ({}, "counter passes skipped (--no-traffic)", {}) if args.no_traffic else live_traffic(args.workload)
-        roof = roofline_of(run, traffic, tnote, tdetail)
-        paired = run["paired_x"]
-        if not args.no_beyond_cache and args.workload == "2d-8192":
-            # the same kernels on a 2-D grid whose vectors are twice the Infinity Cache: the HBM-bound rate
-            ext2, mode2 = workload_extents(BEYOND_CACHE_WORKLOAD)
-            run2 = run_single(lib, ext2, mode2, args.steps, args.warmup, max(3, args.repeats // 2 + 1), not args.no_graph,
-                              barrier, device)
-            t2 = statistics.median(run2["times"])
-            its2 = args.steps / t2
-            extra["beyond_cache"] = dict(
-                {"workload": BEYOND_CACHE_WORKLOAD, "points": run2["N"], "iterations_per_sec": round(its2, 3),
-                 "ms_per_step": round(t2 / args.steps * 1e3, 5),
-                 "ms_per_step_min_max": [round(min(run2["times"]) / args.steps * 1e3, 5),
-                                         round(max(run2["times"]) / args.steps * 1e3, 5)],
-                 "roofline": roofline_of(run2, None, "not collected for this workload")},
-                **iteration_rates(run2["N"], its2, run2["paired_x"]))
-        parallelism = "single"
-    else:
-        from conjugate_gradient_amd.slab import SlabCG
-        b = torch.empty(N, dtype=torch.float32, device=device)
-        x = torch.zeros(N, dtype=torch.float32, device=device)
-        # rank-distinct synthetic right-hand side
-        lib.c.cg_fill_uniform(C.c_void_p(b.data_ptr()), N, 1234 + rank)
-        torch.cuda.synchronize()
-        s = SlabCG(lib, ext, rank=rank, world=world, device=device)
-        comm, comm_note = "collectives", ""
-
-        # Transport: the library's own RCCL calls (graph-captured), the direct xGMI boxes, or the Python-driven
-        # collectives.  A candidate is used only if it could be set up on every rank, reproduced the
-        # collectives' residual history, delivered ghost planes that equal the neighbours' boundary planes
-        # bit for bit, and (with --comm auto) was the fastest in a 30-iteration probe.  The candidates are
-        # tried in child processes first (probe_in_sandbox): a transport that aborts or hangs on this
-        # machine must not take the benchmark down with it.
-        candidates = {"auto": ["rccl", "links"], "rccl": ["rccl"], "links": ["links"], "collectives": []}[args.comm]
-        if args.backend != "nccl" and world > 1:
-            candidates = [c for c in candidates if c != "rccl"]   # rehearsal backends share one GPU: RCCL refuses that
-        probes = {}
-        if candidates:
-            t_coll, hist_c, err_c = slab_probe(s, b, x, barrier, rank, world)
-            if err_c:
-                raise SystemExit(f"probe over the collectives failed: {err_c}")
-            probes["collectives"] = t_coll
-            notes = []
-            for k, name in enumerate(candidates):
-                if args.no_sandbox:
-                    ok, t_new, why = check_candidate(s, name, hist_c, b, x, barrier, rank, world)
-                else:
-                    ok, t_new, why = probe_in_sandbox(name, args, 101 + 7 * k)
-                    seen = [None] * world
-                    if world > 1:
-                        dist.all_gather_object(seen, (ok, t_new, why))
-                    else:
-                        seen = [(ok, t_new, why)]
-                    ok = all(o for o, _, _ in seen)
-                    t_new = max((t for _, t, _ in seen if t is not None), default=None)
-                    why = "; ".join(sorted({w for o, _, w in seen if not o and w}))
-                if ok and t_new is not None:
-                    probes[name] = t_new
-                else:
-                    notes.append(f"{name}: {why}")
-            usable = [c for c in candidates if c in probes]
-            if args.comm == "auto":
-                pick = min(["collectives"] + usable, key=lambda c: probes[c])
-            elif usable:
-                pick = usable[0]
-            else:
-                raise SystemExit(f"--comm {args.comm} unavailable: {'; '.join(notes)}")
-            if pick == "rccl" and not s.enable_rccl():
-                pick = "collectives"
-            if pick == "links" and not s.enable_links():
-                pick = "collectives"
-            comm = {"rccl": "rccl-in-library", "links": "xgmi-links", "collectives": "collectives"}[pick]
-            comm_note = "probe seconds for 30 iterations: " + ", ".join(f"{k} {v:.4f}" for k, v in probes.items())
-            if notes:
-                comm_note += "; " + "; ".join(notes)
-            x.zero_()
-
-        def timed():
-            x.zero_()
-            barrier()
-            s.begin(b, x, 0.0, 1)
-            s.iterate(args.warmup)
-            s.sync()
-            ts = []
-            for _ in range(args.repeats):
-                barrier()
-                t0 = time.perf_counter()
-                s.iterate(args.steps)
-                s.sync()
-                barrier()
-                ts.append(time.perf_counter() - t0)
-            done, res, _ = s.finish()
-            if done != args.warmup + args.steps * args.repeats:
-                raise RuntimeError(f"{done} iterations ran instead of {args.warmup + args.steps * args.repeats}")
-            return ts, res
-
-        ok = 1
-        try:
-            times, res = timed()
-        except RuntimeError as e:
-            if comm == "collectives":
-                raise
-            ok, comm_note = 0, f"timed run over {comm} failed: " + str(e)
-        if comm != "collectives" and not s._all_agree(ok):
-            # a rank lost the fast path under load: everyone goes back to the collectives
-            s.disable_links()
-            s.disable_rccl()
-            comm = "collectives"
-            times, res = timed()
-        parallelism = f"slab{world}"
-        if comm != "collectives":
-            with s._ctx():
-                msA, msB = s.ops.solver.time_kernels(max(10, min(50, args.steps)) // 2 * 2)
-                s.sync()
-            xA, xB = s.ops.solver.links_times()
-            exchange = {"after_A": round(xA, 5), "after_B": round(xB, 5)}
-        else:
-            # over the collectives the kernels cannot be timed in place without the all-reduces between
-            # them: time the same two kernels on this rank's slab with a stand-alone solver
-            had = os.environ.get("CG_XDEFER")
-            os.environ["CG_XDEFER"] = "0"     # as the step interface runs them: x updated by every kernel B
-            t = lib.make_solver(ext, index_mode=mode)
-            if had is None:
-                os.environ.pop("CG_XDEFER")
-            else:
-                os.environ["CG_XDEFER"] = had
-            x.zero_()
-            torch.cuda.synchronize()
-            t.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
-            t.iterate(5, use_graph=False)
-            msA, msB = t.time_kernels(max(10, min(50, args.steps)) // 2 * 2)
-            t.close()
-            exchange = None
-        # the step interface the Python-driven collectives use updates x in every kernel B
-        paired = s.ops.solver.paired_x and comm != "collectives"
-        roof = roofline_of({"N": N, "msA": msA, "msB": msB, "kernel": s.ops.solver.kernel_name, "paired_x": paired},
-                           None, "not collected in multi-rank runs")
-        roof["exchange_ms"] = exchange
-        roof["rank"] = 0
-
-    # every region's time is the maximum over ranks; the median region is reported
-    tmax = torch.tensor(times, dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    times = [float(v) for v in tmax.tolist()]
-    dt = statistics.median(times)
-
-    if rank == 0:
+        dt = statistics.median(times)
         its = args.steps / dt
         out = {
-            "metric": "cg_iterations_per_sec", "value": round(its * (world if args.scaling == "weak" else 1), 3),
-            "unit": ("CG iterations/s of the whole grid (strong scaling)" if args.scaling == "strong" else
-                     "CG iterations/s per 2^%d-point slab, summed over GPUs" % (N.bit_length() - 1)
-                     if (N & (N - 1)) == 0 else "CG iterations/s per slab, summed over GPUs"),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "cg_iterations_per_sec", "value": round(its, 3),
+            "unit": "CG iterations/s per 2^%d-point slab, summed over GPUs" % (N.bit_length() - 1)
+                    if (N & (N - 1)) == 0 else "CG iterations/s per slab, summed over GPUs",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "local_extents": ext, "index_mode": mode,
-                       "points_per_gpu": N, "parallelism": parallelism, "graph": not args.no_graph,
-                       "backend": args.backend if world > 1 else None,
-                       "comm": (comm + (f" ({comm_note})" if comm_note else "")) if parallelism != "single" else None,
-                       "paired_x_update": bool(paired), "rhs": "u01 seed 1234+rank", "x0": 0},
+                       "points_per_gpu": N, "parallelism": "single", "graph": graph, "backend": None, "comm": None,
+                       "kernel": run["kernel"], "paired_x_update": bool(run["paired_x"]), "rhs": "u01 seed 1234+rank", "x0": 0},
             "timing": {"regions": args.repeats, "statistic": "median",
                        "ms_per_step_min_max": [round(min(times) / args.steps * 1e3, 5), round(max(times) / args.steps * 1e3, 5)],
                        "ms_per_step_all": [round(t / args.steps * 1e3, 5) for t in times]},
             "iterations_per_sec_global": round(its, 3),
-            "final_residue": res,
+            "final_residue": run["residue"],
         }
-        out.update(iteration_rates(N * world, its, paired))   # all ranks' points move once per global iteration
-        out.update(extra)
-        if roof:
-            out["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
+        out.update(iteration_rates(N, its, run["paired_x"]))
+        out["roofline"] = roofline_of(run, traffic, tnote, tdetail)
+        if mode == 2 and run["kernel"] not in ("k_morton_tile", "k_morton4"):
+            out.update(morton_both_ways(args, lib, ext, mode, run, barrier, device))
+        if not args.no_beyond_cache and args.workload == "2d-8192":
+            # the same kernels on a 2-D grid whose vectors are twice the Infinity Cache: the HBM-bound rate
+            ext2, mode2 = workload_extents(BEYOND_CACHE_WORKLOAD)
+            run2 = run_single(lib, ext2, mode2, args.steps, args.warmup, max(3, args.repeats // 2 + 1), graph, barrier, device)
+            t2 = statistics.median(run2["times"])
+            its2 = args.steps / t2
+            tr2, tn2, td2 = ({}, "counter passes skipped (--no-traffic)", {}) if args.no_traffic else live_traffic(BEYOND_CACHE_WORKLOAD)
+            out["roofline_hbm_bound"] = dict(
+                {"workload": BEYOND_CACHE_WORKLOAD, "points": run2["N"], "iterations_per_sec": round(its2, 3),
+                 "why": "every vector of this grid is 512 MiB, twice the Infinity Cache: nothing is served on-die",
+                 "ms_per_step": round(t2 / args.steps * 1e3, 5),
+                 "ms_per_step_min_max": [round(min(run2["times"]) / args.steps * 1e3, 5),
+                                         round(max(run2["times"]) / args.steps * 1e3, 5)],
+                 "roofline": roofline_of(run2, tr2, tn2, td2)},
+                **iteration_rates(run2["N"], its2, run2["paired_x"]))
+        if not args.no_cpu_baseline:
             out.update(cpu_baselines_isolated(ext, args.cpu_seconds))
         print(json.dumps(out), flush=True)
+    else:
+        r = run_slab(args, lib, ext, mode, rank, world, device, barrier)
+        out = slab_line(args, ext, mode, args.workload, world, r)
+        # config "3D 1024^3 slab-decomposed over 8 GPUs", as weak scaling of its per-GPU slab, over the same transport
+        if world > 1 and not args.no_config3 and args.workload == "2d-8192" and args.scaling == "weak":
+            ext3, mode3 = workload_extents(CONFIG3_SLAB)
+            try:
+                r3 = run_slab(args, lib, ext3, mode3, rank, world, device, barrier, pick=r["pick"])
+                c3 = slab_line(args, ext3, mode3, CONFIG3_SLAB, world, r3)
+                for k in ("metric", "higher_is_better", "vs_baseline", "dtype", "data", "steps", "warmup", "n_gpus"):
+                    c3.pop(k, None)
+                out["config3"] = c3
+            except RuntimeError as e:
+                out["config3"] = {"failed": str(e)[:300]}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -27,7 +27,8 @@ EXPORTS = [
     "cg_links_box_bytes", "cg_links_alloc", "cg_links_free", "cg_links_peer_ok", "cg_links_export", "cg_links_open",
     "cg_links_close", "cg_links_poke", "cg_links_peek", "cg_solver_bind_links", "cg_solver_exchange", "cg_solver_links_error",
     "cg_solver_links_times", "cg_noalloc_prepare", "cg_inner_product_noalloc",
-    "cg_solver_bind_partials_n", "cg_solver_blocks_of", "cg_release_cache", "cg_rccl_unique_id", "cg_rccl_comm_create", "cg_rccl_comm_destroy", "cg_solver_bind_rccl",
+    "cg_solver_bind_partials_n", "cg_solver_blocks_of", "cg_release_cache", "cg_rccl_unique_id", "cg_rccl_comm_create", "cg_rccl_comm_destroy", "cg_solver_bind_rccl", "cg_solver_rccl_ranks",
+    "cg_solver_bind_rccl_peers", "cg_solver_edge_copy", "cg_solver_edge_update", "cg_solver_edge_plane",
 ]
 
 
@@ -185,6 +186,15 @@ class Library:
         c.cg_rccl_comm_destroy.restype = i32
         c.cg_solver_bind_rccl.argtypes = [vp, vp, i32, i32]
         c.cg_solver_bind_rccl.restype = i32
+        c.cg_solver_bind_rccl_peers.argtypes = [vp, vp, i32, i32, i32, i32]
+        c.cg_solver_bind_rccl_peers.restype = i32
+        for f in ("cg_solver_edge_copy", "cg_solver_edge_update"):
+            getattr(c, f).argtypes = [vp]
+            getattr(c, f).restype = None
+        c.cg_solver_edge_plane.argtypes = [vp, i32]
+        c.cg_solver_edge_plane.restype = C.c_void_p
+        c.cg_solver_rccl_ranks.argtypes = [vp]
+        c.cg_solver_rccl_ranks.restype = i32
         c.cg_noalloc_prepare.argtypes = []
         c.cg_noalloc_prepare.restype = i32
         c.cg_inner_product_noalloc.argtypes = [fp, fp, C.c_ulonglong, fp, vp]
@@ -444,11 +454,29 @@ class Solver:
         else:
             self.lib.c.cg_solver_bind_partials_n(self.h, _ptr(pAp_parts), _ptr(rr_parts), n)
 
-    def bind_rccl(self, comm, rank, world):
-        """comm: an ncclComm_t address (Library.rccl_comm_create); None unbinds.  Collective."""
-        e = self.lib.c.cg_solver_bind_rccl(self.h, _ptr(comm), rank, world)
+    def bind_rccl(self, comm, rank, world, peers=None):
+        """comm: an ncclComm_t address (Library.rccl_comm_create); None unbinds.  peers: (lo_rank, hi_rank) of
+        the slabs below / above, -1 for none; default rank - 1 / rank + 1.  Collective."""
+        if peers is None:
+            e = self.lib.c.cg_solver_bind_rccl(self.h, _ptr(comm), rank, world)
+        else:
+            e = self.lib.c.cg_solver_bind_rccl_peers(self.h, _ptr(comm), rank, world, int(peers[0]), int(peers[1]))
         if e:
             raise RuntimeError(f"cg_solver_bind_rccl failed with ncclResult {e}")
+
+    # r's boundary planes ahead of kernel B (step interface)
+    def edge_copy(self):
+        self.lib.c.cg_solver_edge_copy(self.h)
+
+    def edge_update(self):
+        self.lib.c.cg_solver_edge_update(self.h)
+
+    def edge_plane(self, side):
+        return self.lib.c.cg_solver_edge_plane(self.h, side)
+
+    def rccl_ranks(self):
+        """Ranks of the bound RCCL communicator as RCCL itself counts them (0: none bound)."""
+        return self.lib.c.cg_solver_rccl_ranks(self.h)
 
     def init_state(self, rel, lagged, maxit):
         self.lib.c.cg_solver_init_state(self.h, rel, lagged, maxit)

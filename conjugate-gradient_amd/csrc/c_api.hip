@@ -576,6 +576,9 @@ extern "C" void cg_solver_init_state(cg_solver *s, double rel, int lagged, int m
 extern "C" void cg_solver_add_iterations(cg_solver *s, int n) { s->impl.add_iterations(n); }
 extern "C" void cg_solver_kernel_A(cg_solver *s) { s->impl.launch_A(); }
 extern "C" void cg_solver_kernel_B(cg_solver *s) { s->impl.launch_B(false); } // x complete after every call
+extern "C" void cg_solver_edge_copy(cg_solver *s) { s->impl.edge_copy(s->impl.stream()); }
+extern "C" void cg_solver_edge_update(cg_solver *s) { s->impl.edge_update(s->impl.stream()); }
+extern "C" float *cg_solver_edge_plane(cg_solver *s, int side) { return s->impl.edge_plane(side); }
 extern "C" float *cg_solver_r(cg_solver *s) { return s->impl.r(); }
 extern "C" float *cg_solver_p(cg_solver *s, int which) { return s->impl.p(which); }
 

@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
     }
   }
   if constexpr (MODE != MODE_STENCIL)
-    block_write_partial(acc, a.part_out, sh);
+    block_write_partial(acc, a, sh);
 }
 
 } // namespace cgamd

@@ -51,6 +51,7 @@ namespace cgamd
 constexpr int CG_MAXD = 32;        // scalar engine
 constexpr int CG_ROWS_MAXD = 14;   // rows engine: axes 2..15 (rows of >= 4 points and N < 2^32 allow no more)
 constexpr int CG_MAX_BLOCKS = 2048;
+constexpr int CG_RCCL_MAX_RANKS = 1024; // slots of the gathered per-rank dot products
 constexpr int CG_HIST = 1024;      // ring of r.r values, indexed by iteration mod CG_HIST
 
 enum
@@ -112,6 +113,11 @@ struct VecArgs
   const unsigned long long *push_seq;
   unsigned long long push_stride;
   int xdefer; // kernel B may leave x alone on even iterations (see CgState::xdef_k)
+  // RCCL path: the last workgroup of the launch to finish also adds all of the launch's partials up (fixed
+  // order) into rank_sum[0], so that one double per rank travels; ticket counts the finished workgroups
+  // (device memory, zero between launches).  Null: nobody does.
+  double *rank_sum;
+  unsigned int *ticket;
 };
 
 // staging buffers of this launch: the exchange that follows kernel B is number *push_seq + 1
@@ -218,6 +224,66 @@ __device__ __forceinline__ void block_write_partial(float acc, double *__restric
     for (int i = 0; i < nw; i++)
       s += sh[i];
     part_out[blockIdx.x] = s;
+  }
+}
+
+// block_read_sum of partials other workgroups of THIS launch wrote: every load is a device-scope atomic, which
+// no cache of this workgroup's XCD serves from a stale line
+__device__ __forceinline__ double block_read_sum_fresh(const double *src, int n, double *sh)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  for (int vw = wave; vw < 4; vw += nw)
+  {
+    const int v = vw * 64 + lane;
+    double s = 0;
+    for (int i0 = 0; i0 < n; i0 += 2048)
+    {
+      double t[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+      {
+        const int i = i0 + v + 256 * j;
+        t[j] = i < n ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        s += t[j];
+    }
+    s = wave_sum(s);
+    if (lane == 0)
+      sh[vw] = s;
+  }
+  __syncthreads();
+  const double v = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+  __syncthreads();
+  return v;
+}
+
+// The epilogue of kernels A and B: this workgroup's partial, and -- with a.rank_sum set -- the sum of all the
+// launch's partials by whichever workgroup finishes last, in the order block_read_sum adds them (so
+// rank_sum[0] has the bits a consumer's block_read_sum over the same partials would produce).
+__device__ __forceinline__ void block_write_partial(float acc, const VecArgs &a, double *sh)
+{
+  block_write_partial(acc, a.part_out, sh);
+  if (!a.rank_sum) // uniform over the launch
+    return;
+  __shared__ int is_last;
+  if (threadIdx.x == 0)
+  {
+    // release: the partial above is visible device-wide before the ticket; acquire: whoever draws the last
+    // ticket sees every other workgroup's partial
+    const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1u);
+  }
+  __syncthreads();
+  if (!is_last)
+    return;
+  __threadfence();
+  const double s = block_read_sum_fresh(a.part_out, (int)gridDim.x, sh);
+  if (threadIdx.x == 0)
+  {
+    a.rank_sum[0] = s;
+    __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // for the next launch
   }
 }
 
@@ -757,7 +823,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
     }
   }
   if constexpr (MODE != MODE_STENCIL)
-    block_write_partial(acc, a.part_out, sh);
+    block_write_partial(acc, a, sh);
 }
 
 // ---- scalar engine ---------------------------------------------------------------------
@@ -886,7 +952,7 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
     }
   }
   if constexpr (MODE != MODE_STENCIL)
-    block_write_partial(acc, a.part_out, sh);
+    block_write_partial(acc, a, sh);
 }
 
 // ---- small kernels (defined in cg_solver.hip) ------------------------------------------

@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_morton4(const MortonGeom g, const VecAr
     }
   }
   if constexpr (MODE != MODE_STENCIL)
-    block_write_partial(acc, a.part_out, sh);
+    block_write_partial(acc, a, sh);
 }
 
 
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(CG_MORTON_BT) k_morton_tile(const MortonGeom g
       __syncthreads(); // the single buffer is overwritten by the next tile
   }
   if constexpr (MODE != MODE_STENCIL)
-    block_write_partial(acc, a.part_out, sh);
+    block_write_partial(acc, a, sh);
 }
 
 } // namespace cgamd

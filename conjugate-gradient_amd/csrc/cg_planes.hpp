@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
     store_ghost(zs + dir * nz, pc);
   }
   if constexpr (MODE != MODE_STENCIL)
-    block_write_partial(acc, a.part_out, sh);
+    block_write_partial(acc, a, sh);
 }
 
 } // namespace cgamd

@@ -1,15 +1,20 @@
-// cg_rccl.hip -- the multi-GPU exchange on RCCL (over xGMI inside a node): the dot-product all-reduces and
-// the halo exchange of the slab decomposition, enqueued by the library itself on the solver's stream.
+// cg_rccl.hip -- the multi-GPU exchange on RCCL (over xGMI inside a node): the dot-product exchanges and
+// the halo exchange of the slab decomposition, enqueued by the library itself.
 //
 // One rank per GPU; rank r owns slab r of the grid cut along its slowest axis.  Per CG iteration:
-//   after kernel A   ncclAllReduce(sum) of the per-workgroup partials of p.Ap       (<= 32 KiB of doubles)
-//   after kernel B   ncclAllReduce(sum) of the partials of r.r, then one grouped
-//                    ncclSend / ncclRecv pair per neighbour: r's first / last owned hyperplane into the
-//                    neighbour's ghost plane (only r is exchanged; kernel A rebuilds p on the ghost planes)
-// The partials are reduced element-wise, not pre-summed: the consumer kernel adds the reduced array in its
-// usual fixed order, so no extra reduction launch exists and every rank derives alpha, beta and the stop
-// decision from the same bits (an all-reduce hands every rank the same result).  Ranks may own different
-// numbers of workgroups: all of them reduce max-over-ranks entries, the tail of a shorter array stays zero.
+//   after kernel A   ncclAllGather of ONE double per rank: this rank's p.Ap, added up in the fixed order by
+//                    the last workgroup of kernel A to finish (no reduction launch); kernel B's prologue
+//                    adds the `world` doubles in a fixed order
+//   after kernel B   the same for r.r
+//   beside kernel B  on a second stream and a communicator of its own: the two boundary planes r will have
+//                    after this iteration are computed ahead of kernel B from a copy of the planes taken
+//                    beside kernel A (Solver::edge_update, ~8 planes of traffic), then one grouped
+//                    ncclSend / ncclRecv pair per neighbour puts them into the neighbours' ghost planes of r,
+//                    which nothing reads before the next kernel A.  Only r is exchanged; kernel A rebuilds p
+//                    on the ghost planes.
+// Critical path of an iteration: kernel A, all-gather (8 bytes per rank), kernel B, all-gather; the planes
+// (4 MiB each way per neighbour on a 1024 x 1024 x 128 slab) are off it.  Every rank adds the same doubles in
+// the same order, so alpha, beta and the stop decision agree bit for bit.
 // The reference has no multi-GPU code; its loop (conjugate-gradient_gpu.cu:349-370) is what every rank runs.
 #include <rccl/rccl.h>
 #include <stdio.h>
@@ -45,11 +50,41 @@ namespace cgamd
     }                                                                                                    \
   }
 
-int Solver::bind_rccl(void *comm, int rank, int world)
+double *Solver::gathered(int which) const { return rank_sums_ + 2 + (size_t)which * CG_RCCL_MAX_RANKS; }
+
+unsigned int *Solver::ticket(int which) const
+{
+  return reinterpret_cast<unsigned int *>(rank_sums_ + 2 + 2 * (size_t)CG_RCCL_MAX_RANKS) + which;
+}
+
+void Solver::rccl_release()
+{
+  if (own_halo_comm_ && comm_halo_)
+  {
+    const ncclResult_t rc = ncclCommDestroy(static_cast<ncclComm_t>(comm_halo_));
+    if (rc != ncclSuccess)
+      fprintf(stderr, "RCCL: destroying the halo communicator failed: %s\n", ncclGetErrorString(rc));
+  }
+  comm_halo_ = nullptr;
+  own_halo_comm_ = false;
+}
+
+int Solver::rccl_ranks() const
+{
+  int n = 0;
+  if (rccl_ && ncclCommCount(static_cast<ncclComm_t>(comm_), &n) != ncclSuccess)
+    n = -1;
+  return n;
+}
+
+int Solver::bind_rccl(void *comm, int rank, int world, int lo_rank, int hi_rank)
 {
   CHECK(hipStreamSynchronize(stream_));
+  if (side_)
+    CHECK(hipStreamSynchronize(side_));
   if (!comm)
   {
+    rccl_release();
     rccl_ = false;
     comm_ = nullptr;
     partA_ = partA_own_;
@@ -58,70 +93,94 @@ int Solver::bind_rccl(void *comm, int rank, int world)
     return 0;
   }
   CG_REQUIRE(!linked_, "boxes are bound: unbind them before binding a communicator");
-  CG_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank out of range");
-  CG_REQUIRE((desc_.has_lo != 0) == (rank > 0) && (desc_.has_hi != 0) == (rank + 1 < world),
-             "has_lo / has_hi of the solver do not match its rank");
+  CG_REQUIRE(world >= 1 && world <= CG_RCCL_MAX_RANKS && rank >= 0 && rank < world, "rank out of range");
+  CG_REQUIRE(lo_rank >= -1 && lo_rank < world && hi_rank >= -1 && hi_rank < world, "neighbour rank out of range");
+  CG_REQUIRE((desc_.has_lo != 0) == (lo_rank >= 0) && (desc_.has_hi != 0) == (hi_rank >= 0),
+             "has_lo / has_hi of the solver do not match its neighbour ranks");
   ncclComm_t c = static_cast<ncclComm_t>(comm);
   int n = 0, r = -1;
   RCCL_TRY(ncclCommCount(c, &n));
   RCCL_TRY(ncclCommUserRank(c, &r));
   CG_REQUIRE(n == world && r == rank, "rank / world do not match the communicator");
-  const size_t np = 2 * CG_MAX_BLOCKS;
-  if (!sum_bufs_)
-    CHECK(hipMalloc((void **)&sum_bufs_, 2 * np * sizeof(double)));
-  CHECK(hipMemset(sum_bufs_, 0, 2 * np * sizeof(double)));
+  const size_t bytes = (2 + 2 * (size_t)CG_RCCL_MAX_RANKS) * sizeof(double) + 16;
+  if (!rank_sums_)
+    CHECK(hipMalloc((void **)&rank_sums_, bytes));
+  CHECK(hipMemset(rank_sums_, 0, bytes));
   partA_ = partA_own_;
   partB_ = partB_own_;
-  // what a kernel does not write must read as zero on every rank
-  CHECK(hipMemset(partA_own_, 0, np * sizeof(double)));
-  CHECK(hipMemset(partB_own_, 0, np * sizeof(double)));
-  // the common length of the reduced arrays; this first collective also sets the connections up outside
-  // any stream capture
-  int *cnt = reinterpret_cast<int *>(sum_bufs_);
-  int mine = grid_;
-  CHECK(hipMemcpy(cnt, &mine, sizeof(int), hipMemcpyHostToDevice));
-  RCCL_TRY(ncclAllReduce(cnt, cnt + 1, 1, ncclInt, ncclMax, c, stream_));
-  CHECK(hipStreamSynchronize(stream_));
-  int most = 0;
-  CHECK(hipMemcpy(&most, cnt + 1, sizeof(int), hipMemcpyDeviceToHost));
-  CG_REQUIRE(most >= grid_ && most <= (int)np, "unexpected number of partial sums across the ranks");
-  CHECK(hipMemset(sum_bufs_, 0, 2 * sizeof(int)));
-  nparts_all_ = most;
+  // what a kernel does not write must read as zero
+  CHECK(hipMemset(partA_own_, 0, 2 * CG_MAX_BLOCKS * sizeof(double)));
+  CHECK(hipMemset(partB_own_, 0, 2 * CG_MAX_BLOCKS * sizeof(double)));
+  // nothing may be allocated or created once a capture is open: do it all here
+  ensure_edge();
+  ensure_side();
+  // the plane exchange runs beside the dot-product exchanges: a communicator of its own keeps the two
+  // independent (collective; if RCCL cannot split, the planes share comm and RCCL orders them itself)
+  rccl_release();
+  ncclComm_t halo = nullptr;
+  const ncclResult_t sp = ncclCommSplit(c, 0, rank, &halo, nullptr);
+  if (sp == ncclSuccess && halo)
+  {
+    comm_halo_ = halo;
+    own_halo_comm_ = true;
+  }
+  else
+  {
+    fprintf(stderr, "RCCL: ncclCommSplit failed (%s); boundary planes share the communicator\n", ncclGetErrorString(sp));
+    comm_halo_ = comm;
+  }
   comm_ = comm;
   comm_rank_ = rank;
   comm_world_ = world;
+  lo_rank_ = lo_rank;
+  hi_rank_ = hi_rank;
   rccl_ = true;
-  bind_sums(sum_bufs_, most, sum_bufs_ + np, most);
-  // the neighbour connections as well (r's ghost planes receive the boundary planes of the zeroed r)
-  rccl_exchange_planes();
+  bind_sums(gathered(0), world, gathered(1), world);
+  // set every connection up outside any stream capture: one all-gather, one plane exchange (r's ghost
+  // planes receive boundary planes of whatever r holds; the next begin() overwrites them)
+  rccl_allgather(0);
+  rccl_exchange_from_r();
   CHECK(hipStreamSynchronize(stream_));
+  CHECK(hipMemset(rank_sums_, 0, bytes));
   return 0;
 }
 
-void Solver::rccl_allreduce(int which)
+void Solver::rccl_allgather(int which)
 {
-  const size_t np = 2 * CG_MAX_BLOCKS;
-  RCCL_CHECK(ncclAllReduce(which ? partB_ : partA_, sum_bufs_ + (which ? np : 0), (size_t)nparts_all_, ncclDouble,
-                           ncclSum, static_cast<ncclComm_t>(comm_), stream_));
+  RCCL_CHECK(ncclAllGather(&rank_sums_[which], gathered(which), 1, ncclDouble, static_cast<ncclComm_t>(comm_), stream_));
 }
 
-void Solver::rccl_exchange_planes()
+// to_lo / to_hi: what the rank below / above receives into its hi / lo ghost plane of r; what they send lands
+// in this rank's ghost planes.  A rank that is its own neighbour on both sides (a ring of one, used to test
+// this path on one GPU) receives its sends in the order it posted them.
+void Solver::rccl_send_recv(const float *to_lo, const float *to_hi, hipStream_t s)
 {
-  if (!desc_.has_lo && !desc_.has_hi)
+  if (lo_rank_ < 0 && hi_rank_ < 0)
     return;
-  ncclComm_t c = static_cast<ncclComm_t>(comm_);
+  ncclComm_t c = static_cast<ncclComm_t>(comm_halo_);
   RCCL_CHECK(ncclGroupStart());
-  if (desc_.has_lo)
+  if (lo_rank_ >= 0)
   {
-    RCCL_CHECK(ncclSend(r_, plane_, ncclFloat, comm_rank_ - 1, c, stream_));
-    RCCL_CHECK(ncclRecv(r_ - plane_, plane_, ncclFloat, comm_rank_ - 1, c, stream_));
+    RCCL_CHECK(ncclSend(to_lo, plane_, ncclFloat, lo_rank_, c, s));
+    RCCL_CHECK(ncclRecv(r_ - plane_, plane_, ncclFloat, lo_rank_, c, s));
   }
-  if (desc_.has_hi)
+  if (hi_rank_ >= 0)
   {
-    RCCL_CHECK(ncclSend(r_ + N_ - plane_, plane_, ncclFloat, comm_rank_ + 1, c, stream_));
-    RCCL_CHECK(ncclRecv(r_ + N_, plane_, ncclFloat, comm_rank_ + 1, c, stream_));
+    RCCL_CHECK(ncclSend(to_hi, plane_, ncclFloat, hi_rank_, c, s));
+    RCCL_CHECK(ncclRecv(r_ + N_, plane_, ncclFloat, hi_rank_, c, s));
   }
   RCCL_CHECK(ncclGroupEnd());
+}
+
+void Solver::rccl_exchange_from_r()
+{
+  if (lo_rank_ < 0 && hi_rank_ < 0)
+    return;
+  CHECK(hipEventRecord(ev_fork_, stream_));
+  CHECK(hipStreamWaitEvent(side_, ev_fork_, 0));
+  rccl_send_recv(r_, r_ + N_ - plane_, side_);
+  CHECK(hipEventRecord(ev_join_, side_));
+  CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
 }
 
 } // namespace cgamd
@@ -161,5 +220,13 @@ Solver &cg_solver_impl(cg_solver *s);
 
 extern "C" int cg_solver_bind_rccl(cg_solver *s, void *comm, int rank, int world)
 {
-  return cg_solver_impl(s).bind_rccl(comm, rank, world);
+  // slab r lies between slabs r - 1 and r + 1
+  return cg_solver_impl(s).bind_rccl(comm, rank, world, rank > 0 ? rank - 1 : -1, rank + 1 < world ? rank + 1 : -1);
 }
+
+extern "C" int cg_solver_bind_rccl_peers(cg_solver *s, void *comm, int rank, int world, int lo_rank, int hi_rank)
+{
+  return cg_solver_impl(s).bind_rccl(comm, rank, world, lo_rank, hi_rank);
+}
+
+extern "C" int cg_solver_rccl_ranks(cg_solver *s) { return cg_solver_impl(s).rccl_ranks(); }

@@ -146,6 +146,63 @@ __global__ void __launch_bounds__(64) k_set_maxit(CgState *st, int add)
     st->maxit = st->itA + add;
 }
 
+// r's first / last owned hyperplane as kernel B of the coming iteration will leave it, computed ahead of that
+// kernel from a copy of the planes: edge[side][j] = fma(-alpha, (A p)[point], edge[side][j]) with the stencil
+// terms added in axis order and alpha formed exactly as kernel B's prologue forms it, so the bits are kernel
+// B's.  Reads p (which kernel B only reads) and words of the state kernel A wrote; never touches r.
+// Nothing happens when the iteration is inactive: the copy then is what r keeps.
+struct EdgeArgs
+{
+  const float *p0, *p1;
+  const CgState *st;
+  const double *sumA;
+  int nA;
+  float *edge;
+  unsigned long long plane, pad;
+};
+
+__global__ void __launch_bounds__(256) k_edge_r(const ScalarGeom g, const EdgeArgs e)
+{
+  __shared__ double sh[8];
+  const CgState *st = e.st;
+  const int k = st->itB;
+  const bool active = st->activeB != 0;
+  const float pAp = (float)block_read_sum(e.sumA, e.nA, sh);
+  if (!active)
+    return;
+  const float alpha = st->rr_hist[k % CG_HIST] / pAp;
+  const float *__restrict__ p = (k & 1) ? e.p0 : e.p1;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (int side = 0; side < 2; side++)
+  {
+    if (side == 0 ? !g.has_lo : !g.has_hi)
+      continue;
+    const unsigned long long first = side == 0 ? 0ull : g.N - e.plane;
+    float *__restrict__ out = e.edge + (size_t)side * e.pad;
+    for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < e.plane; j += step)
+    {
+      const long long i = (long long)(first + j);
+      const float c = p[i];
+      float lv = 0.0f;
+      unsigned rem = (unsigned)i;
+      for (int a = 0; a < g.d; a++)
+      {
+        const unsigned nk = g.n[a];
+        const unsigned ck = rem % nk;
+        rem /= nk;
+        const long long s = (long long)g.stride[a];
+        const bool last = a == g.d - 1; // the slab axis: ghost planes hold the neighbours' values
+        const bool hp = (ck + 1 < nk) || (last && g.has_hi);
+        const bool hm = (ck > 0) || (last && g.has_lo);
+        const float up = hp ? p[i + s] : 0.0f;
+        const float um = hm ? p[i - s] : 0.0f;
+        lv = lv + axis_term(up, c, um);
+      }
+      out[j] = fmaf(-alpha, lv, out[j]);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_fill_uniform(float *__restrict__ dst, unsigned long long n, unsigned int seed)
 {
   const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
@@ -569,6 +626,8 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
 Solver::~Solver()
 {
   (void)hipStreamSynchronize(stream_);
+  if (side_)
+    (void)hipStreamSynchronize(side_);
   if (graph_)
     (void)hipGraphExecDestroy(graph_);
   if (tail_graph_)
@@ -582,8 +641,19 @@ Solver::~Solver()
   (void)hipFree(partA_own_);
   (void)hipFree(partB_own_);
   (void)hipFree(st_);
-  if (sum_bufs_)
-    (void)hipFree(sum_bufs_);
+  rccl_release();
+  if (rank_sums_)
+    (void)hipFree(rank_sums_);
+  if (edge_)
+    (void)hipFree(edge_);
+  for (hipEvent_t e : {ev_fork_, ev_copy_, ev_alpha_, ev_join_})
+    if (e)
+      (void)hipEventDestroy(e);
+  if (side_)
+  {
+    (void)hipStreamSynchronize(side_);
+    (void)hipStreamDestroy(side_);
+  }
   if (xpad_)
     (void)hipFree(xpad_);
   if (link_ctl_)
@@ -731,8 +801,10 @@ size_t Solver::device_bytes() const
   n += ((own_r_ ? 1 : 0) + (own_p0_ ? 1 : 0) + (own_p1_ ? 1 : 0)) * buflen_ * sizeof(float);
   if (xpad_)
     n += Np_ * sizeof(float);
-  if (sum_bufs_)
-    n += 2 * (size_t)(2 * CG_MAX_BLOCKS) * sizeof(double);
+  if (rank_sums_)
+    n += (2 + 2 * (size_t)CG_RCCL_MAX_RANKS) * sizeof(double) + 16;
+  if (edge_)
+    n += 2 * edge_pad_ * sizeof(float);
   if (link_ctl_)
     n += sizeof(LinkCtl);
   return n;
@@ -964,6 +1036,11 @@ void Solver::launch_A()
 {
   VecArgs a = args();
   a.part_out = partA_;
+  if (rccl_)
+  {
+    a.rank_sum = &rank_sums_[0];
+    a.ticket = ticket(0);
+  }
   launch_mode(MODE_A, true, a);
 }
 
@@ -989,6 +1066,11 @@ void Solver::launch_B(bool may_defer)
   a.xdefer = (xdefer_ && may_defer) ? 1 : 0;
   if (a.xdefer)
     may_be_pending_ = true;
+  if (rccl_)
+  {
+    a.rank_sum = &rank_sums_[1];
+    a.ticket = ticket(1);
+  }
   if (linked_ && push_in_b_ && (desc_.has_lo || desc_.has_hi))
   {
     // r's boundary planes travel while kernel B still runs: it stores them into the neighbours' staging
@@ -1222,10 +1304,66 @@ void Solver::begin(const float *b_dev, float *x_dev, double rel, int lagged)
     launch_exchange(1, true);
   else if (rccl_)
   {
-    rccl_allreduce(1);
-    rccl_exchange_planes();
+    reduce_partials(1, &rank_sums_[1]);
+    rccl_allgather(1);
+    rccl_exchange_from_r();
   }
   init_state(rel, lagged, 0);
+}
+
+// ---- r's boundary planes ahead of kernel B ---------------------------------------------------------------
+
+void Solver::ensure_edge()
+{
+  if (edge_)
+    return;
+  edge_pad_ = (plane_ + 63) / 64 * 64;
+  CHECK(hipMalloc((void **)&edge_, 2 * edge_pad_ * sizeof(float)));
+  CHECK(hipMemset(edge_, 0, 2 * edge_pad_ * sizeof(float)));
+}
+
+void Solver::ensure_side()
+{
+  if (side_)
+    return;
+  CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+  for (hipEvent_t *e : {&ev_fork_, &ev_copy_, &ev_alpha_, &ev_join_})
+    CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+}
+
+float *Solver::edge_plane(int side)
+{
+  ensure_edge();
+  return edge_ + (side ? edge_pad_ : 0);
+}
+
+void Solver::edge_copy(hipStream_t s)
+{
+  CG_REQUIRE(layout_ == LAYOUT_LEX && !pad_, "boundary planes exist for lexicographic slabs only");
+  ensure_edge();
+  if (desc_.has_lo)
+    CHECK(hipMemcpyAsync(edge_, r_, plane_ * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (desc_.has_hi)
+    CHECK(hipMemcpyAsync(edge_ + edge_pad_, r_ + N_ - plane_, plane_ * sizeof(float), hipMemcpyDeviceToDevice, s));
+}
+
+void Solver::edge_update(hipStream_t s)
+{
+  if (!desc_.has_lo && !desc_.has_hi)
+    return;
+  ensure_edge();
+  EdgeArgs e{};
+  e.p0 = p0_;
+  e.p1 = p1_;
+  e.st = st_;
+  e.sumA = sumA_;
+  e.nA = nA_;
+  e.edge = edge_;
+  e.plane = plane_;
+  e.pad = edge_pad_;
+  const int blocks = (int)std::max<size_t>(1, std::min<size_t>((plane_ + 255) / 256, 256));
+  hipLaunchKernelGGL(k_edge_r, dim3(blocks), dim3(256), 0, s, sg_, e);
+  CHECK(hipGetLastError());
 }
 
 void Solver::bind_links(int rank, int world, void *const *boxes)
@@ -1321,21 +1459,50 @@ void Solver::links_times(float *ms_xA, float *ms_xB) const
     *ms_xB = ms_xB_;
 }
 
-void Solver::launch_iteration()
+void Solver::launch_iteration(hipEvent_t *ev)
 {
+  // with a communicator bound and slab neighbours, r's boundary planes travel on the side stream while kernel
+  // B runs: [side] copy of the planes (beside kernel A) -> [after the p.Ap exchange] edge_update -> send / recv
+  // into the neighbours' ghost planes of r, which nothing reads before the next kernel A
+  const bool halo = rccl_ && (desc_.has_lo || desc_.has_hi);
+  if (ev)
+    CHECK(hipEventRecord(ev[0], stream_));
+  if (halo)
+  {
+    CHECK(hipEventRecord(ev_fork_, stream_)); // r is final: the previous kernel B is behind this point
+    CHECK(hipStreamWaitEvent(side_, ev_fork_, 0));
+    edge_copy(side_);
+    CHECK(hipEventRecord(ev_copy_, side_));
+  }
   launch_A();
+  if (ev)
+    CHECK(hipEventRecord(ev[1], stream_));
   if (linked_)
     launch_exchange(0, false);
   else if (rccl_)
-    rccl_allreduce(0);
+    rccl_allgather(0);
+  if (ev)
+    CHECK(hipEventRecord(ev[2], stream_));
+  if (halo)
+  {
+    CHECK(hipEventRecord(ev_alpha_, stream_)); // every rank's p.Ap is in: alpha can be formed
+    CHECK(hipStreamWaitEvent(side_, ev_alpha_, 0));
+    edge_update(side_);
+    rccl_send_recv(edge_, edge_ + edge_pad_, side_);
+    CHECK(hipEventRecord(ev_join_, side_));
+    CHECK(hipStreamWaitEvent(stream_, ev_copy_, 0)); // kernel B overwrites what the copy reads
+  }
   launch_B();
+  if (ev)
+    CHECK(hipEventRecord(ev[3], stream_));
   if (linked_)
     launch_exchange(1, false);
   else if (rccl_)
-  {
-    rccl_allreduce(1);
-    rccl_exchange_planes();
-  }
+    rccl_allgather(1);
+  if (halo)
+    CHECK(hipStreamWaitEvent(stream_, ev_join_, 0)); // the next kernel A reads r's ghost planes
+  if (ev)
+    CHECK(hipEventRecord(ev[4], stream_));
 }
 
 template <int LAYOUT>
@@ -1498,26 +1665,7 @@ void Solver::time_kernels(int n, float *ms_A, float *ms_B)
     CHECK(hipEventCreate(&e));
   add_iterations(n);
   for (int i = 0; i < n; i++)
-  {
-    CHECK(hipEventRecord(ev[5 * i], stream_));
-    launch_A();
-    CHECK(hipEventRecord(ev[5 * i + 1], stream_));
-    if (linked_)
-      launch_exchange(0, false);
-    else if (rccl_)
-      rccl_allreduce(0);
-    CHECK(hipEventRecord(ev[5 * i + 2], stream_));
-    launch_B();
-    CHECK(hipEventRecord(ev[5 * i + 3], stream_));
-    if (linked_)
-      launch_exchange(1, false);
-    else if (rccl_)
-    {
-      rccl_allreduce(1);
-      rccl_exchange_planes();
-    }
-    CHECK(hipEventRecord(ev[5 * i + 4], stream_));
-  }
+    launch_iteration(&ev[5 * (size_t)i]);
   flush_x();
   CHECK(hipStreamSynchronize(stream_));
   double t[4] = {0, 0, 0, 0};

@@ -105,18 +105,33 @@ public:
   int links_error();                          // synchronises; 1 if a wait ever ran out of time
   void links_times(float *ms_xA, float *ms_xB) const; // exchange launches, from the last time_kernels
 
+  // ---- r's boundary planes ahead of kernel B (what lets the halo exchange run beside kernel B) ----------
+  // edge_copy: the edge buffers take r's first / last owned hyperplane (r as the previous kernel B left it);
+  // edge_update: they become what kernel B of the coming iteration will leave in those planes, bit for bit
+  // (needs the sum of p.Ap bound, i.e. runs after kernel A's dot product has been exchanged).  Both are
+  // enqueued on `s`; neither touches r, so they may run while kernel B does.
+  void edge_copy(hipStream_t s);
+  void edge_update(hipStream_t s);
+  float *edge_plane(int side); // 0: the first owned plane (for the rank below), 1: the last (for the rank above)
+
   // ---- RCCL path: with a communicator bound, begin / iterate / finish run the multi-rank solve by
-  // themselves.  After kernel A one ncclAllReduce of the per-workgroup partials of p.Ap, after kernel B one of
-  // r.r and a grouped ncclSend / ncclRecv of r's boundary planes with the slab neighbours, all enqueued on
-  // stream() and captured in the same hipGraph as the kernels (no host work inside the loop).
+  // themselves.  After kernel A one ncclAllGather of one double per rank (this rank's p.Ap, added up by the
+  // kernel's last workgroup), after kernel B one of r.r; r's boundary planes travel on a second stream while
+  // kernel B runs (edge_update, then a grouped ncclSend / ncclRecv on a communicator of its own), joined
+  // before the next kernel A.  Everything is captured in the same hipGraph as the kernels (no host work
+  // inside the loop).
   // comm: an ncclComm_t whose rank r holds slab r (cg_rccl.hip creates one from a unique id); nullptr unbinds.
+  // lo_rank / hi_rank: the ranks that own the slab below / above (-1: none; must agree with has_lo / has_hi).
   // Returns an ncclResult_t value, 0 = success.  Collective: every rank of the communicator calls it.
-  int bind_rccl(void *comm, int rank, int world);
+  int bind_rccl(void *comm, int rank, int world, int lo_rank, int hi_rank);
   bool rccl_bound() const { return rccl_; }
+  int rccl_ranks() const; // ranks of the bound communicator as RCCL counts them (0: none bound)
 
 private:
   void build_geometry();
-  void launch_iteration(); // A, B and, with boxes bound, the exchange after each
+  // A, B and, with boxes or a communicator bound, the exchanges; ev (5 events, may be null) are recorded
+  // before A, after A, after A's exchange, after B, after B's exchange
+  void launch_iteration(hipEvent_t *ev = nullptr);
   void launch_mode(int mode, bool ghost, const VecArgs &a);
   VecArgs args() const;
 
@@ -164,10 +179,24 @@ private:
   bool rccl_ = false;
   void *comm_ = nullptr;     // ncclComm_t
   int comm_rank_ = 0, comm_world_ = 1;
-  int nparts_all_ = 0;       // the largest blocks() over the ranks: what every all-reduce carries
-  double *sum_bufs_ = nullptr; // [2][2 * CG_MAX_BLOCKS] all-reduced partials of p.Ap / r.r
-  void rccl_allreduce(int which);
-  void rccl_exchange_planes();
+  int lo_rank_ = -1, hi_rank_ = -1;
+  void *comm_halo_ = nullptr; // ncclComm_t for the plane exchange (split off comm_; comm_ itself if that failed)
+  bool own_halo_comm_ = false;
+  // rank_sums_[0..1]: this rank's p.Ap / r.r; then [2][CG_RCCL_MAX_RANKS] every rank's, gathered; then two tickets
+  double *rank_sums_ = nullptr;
+  double *gathered(int which) const;
+  unsigned int *ticket(int which) const;
+  void rccl_allgather(int which);
+  void rccl_send_recv(const float *to_lo, const float *to_hi, hipStream_t s);
+  void rccl_exchange_from_r(); // r's boundary planes as they are now (start of a solve), on the side stream
+  void rccl_release();
+  // second stream and the events that tie it to stream_ (also inside a capture)
+  hipStream_t side_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_copy_ = nullptr, ev_alpha_ = nullptr, ev_join_ = nullptr;
+  void ensure_side();
+  float *edge_ = nullptr;    // [2][edge_pad_]
+  size_t edge_pad_ = 0;
+  void ensure_edge();
   bool linked_ = false;
   bool push_in_b_ = true;    // kernel B stores r's boundary planes into the neighbours' staging areas itself
   LinkArgs links_{};

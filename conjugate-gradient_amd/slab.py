@@ -11,9 +11,11 @@ iteration the ranks exchange
 
 Three transports carry that traffic, the kernels are the same:
 
-  * `enable_rccl()` -- the library issues the RCCL calls itself (csrc/cg_rccl.hip: ncclAllReduce of the
-    partials, grouped ncclSend / ncclRecv of the planes) on the solver's stream, captured in the same
-    hipGraph as the kernels: no host work inside the loop.  The default on GPUs.
+  * `enable_rccl()` -- the library issues the RCCL calls itself (csrc/cg_rccl.hip: ncclAllGather of one
+    double per rank for each dot product; the planes, computed ahead of kernel B, travel by grouped
+    ncclSend / ncclRecv on a second stream while kernel B runs), captured in the same hipGraph as the
+    kernels: no host work inside the loop.  Never run on more than one GPU so far: callers enable it only
+    after a self-check against the collectives below (bench.py does).
   * `enable_links()` -- the ranks of one node write the same data straight into each other's HBM over
     xGMI from a small kernel after A and after B (csrc/cg_links.hpp); four launches per iteration,
     replayed from a hipGraph.
@@ -74,6 +76,22 @@ class HipSlabOps:
         self.parts.zero_()
         torch.cuda.synchronize(self.device)
         self.solver.bind_partials(self.parts[0].data_ptr(), self.parts[1].data_ptr(), self.nparts)
+
+        # the planes r's boundary will hold after the coming kernel B, computed ahead of it by the library
+        # (cg_solver_edge_copy / cg_solver_edge_update): library memory, viewed as tensors for the collectives
+        self.edge_lo = self._view(self.solver.edge_plane(0), self.plane) if has_lo else None
+        self.edge_hi = self._view(self.solver.edge_plane(1), self.plane) if has_hi else None
+
+    def _view(self, ptr, n):
+        class Raw:
+            __cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(Raw(), device=self.device)
+
+    def edge_copy(self):
+        self.solver.edge_copy()
+
+    def edge_update(self):
+        self.solver.edge_update()
 
     def stream_ctx(self):
         return torch.cuda.stream(self.stream)
@@ -164,19 +182,22 @@ class SlabCG:
     def _global_rank(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
 
-    def exchange_r(self):
-        """Boundary planes of r to the neighbours' ghost planes (both directions at once)."""
+    def exchange_r(self, ahead=False):
+        """Boundary planes of r to the neighbours' ghost planes (both directions at once).  ahead: send the
+        planes computed ahead of kernel B (ops.edge_lo / edge_hi: the same bits) instead of r's own."""
         if self.world == 1:
             return
+        first = self.ops.edge_lo if ahead and self.has_lo else self.r_first
+        last = self.ops.edge_hi if ahead and self.has_hi else self.r_last
         if self._host_staged(self.r_first):
-            self._exchange_r_host_staged()
+            self._exchange_r_host_staged(first, last)
             return
         ops = []
         if self.has_lo:
-            ops.append(dist.P2POp(dist.isend, self.r_first, self._global_rank(self.rank - 1), self.group))
+            ops.append(dist.P2POp(dist.isend, first, self._global_rank(self.rank - 1), self.group))
             ops.append(dist.P2POp(dist.irecv, self.r_ghost_lo, self._global_rank(self.rank - 1), self.group))
         if self.has_hi:
-            ops.append(dist.P2POp(dist.isend, self.r_last, self._global_rank(self.rank + 1), self.group))
+            ops.append(dist.P2POp(dist.isend, last, self._global_rank(self.rank + 1), self.group))
             ops.append(dist.P2POp(dist.irecv, self.r_ghost_hi, self._global_rank(self.rank + 1), self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
@@ -197,15 +218,15 @@ class SlabCG:
     def _host_staged(self, t):
         return t.is_cuda and dist.get_backend(self.group) == "gloo"
 
-    def _exchange_r_host_staged(self):
+    def _exchange_r_host_staged(self, first, last):
         reqs, recvs = [], []
         if self.has_lo:
-            reqs.append(dist.isend(self.r_first.cpu(), self._global_rank(self.rank - 1), self.group))
+            reqs.append(dist.isend(first.cpu(), self._global_rank(self.rank - 1), self.group))
             buf = torch.empty(self.r_ghost_lo.shape, dtype=self.r_ghost_lo.dtype)
             reqs.append(dist.irecv(buf, self._global_rank(self.rank - 1), self.group))
             recvs.append((self.r_ghost_lo, buf))
         if self.has_hi:
-            reqs.append(dist.isend(self.r_last.cpu(), self._global_rank(self.rank + 1), self.group))
+            reqs.append(dist.isend(last.cpu(), self._global_rank(self.rank + 1), self.group))
             buf = torch.empty(self.r_ghost_hi.shape, dtype=self.r_ghost_hi.dtype)
             reqs.append(dist.irecv(buf, self._global_rank(self.rank + 1), self.group))
             recvs.append((self.r_ghost_hi, buf))
@@ -416,12 +437,19 @@ class SlabCG:
                 self.ops.solver.iterate(n, True)
                 return
             self.ops.add_iterations(n)
+            # the planes that travel are the ones computed ahead of kernel B (as in the library's RCCL path,
+            # where that lets them travel beside kernel B; here everything shares one stream)
+            ahead = hasattr(self.ops, "edge_update") and self.world > 1
             for _ in range(n):
+                if ahead:
+                    self.ops.edge_copy()
                 self.ops.kernel_A()
                 self.allreduce(0)
+                if ahead:
+                    self.ops.edge_update()
                 self.ops.kernel_B()
                 self.allreduce(1)
-                self.exchange_r()
+                self.exchange_r(ahead)
 
     def finish(self, hist_len=0):
         out = self.ops.finish(hist_len)

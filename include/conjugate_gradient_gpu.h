@@ -216,6 +216,17 @@ extern "C"
   void cg_solver_add_iterations(cg_solver *s, int n);
   void cg_solver_kernel_A(cg_solver *s);
   void cg_solver_kernel_B(cg_solver *s);
+  /* r's boundary planes ahead of kernel B, for callers that want the halo exchange to run beside kernel B
+   * instead of after it.  cg_solver_edge_copy: two internal planes take r's first / last owned hyperplane
+   * (call it while r is as the previous kernel B left it: before, or beside, kernel A).
+   * cg_solver_edge_update (after the sum of p.Ap is bound, i.e. after kernel A's dot product has been
+   * exchanged): the planes become what kernel B of the coming iteration will leave in r there, bit for bit;
+   * it never touches r.  cg_solver_edge_plane(s, 0 / 1): the plane for the rank below / above (device
+   * pointer, cg_solver_plane() floats) -- send it instead of r's own plane.  Asynchronous on the solver's
+   * stream.  Lexicographic slabs only. */
+  void cg_solver_edge_copy(cg_solver *s);
+  void cg_solver_edge_update(cg_solver *s);
+  float *cg_solver_edge_plane(cg_solver *s, int side);
   /* first owned element of r / p.  (A stand-alone grid whose axis 0 is not a multiple of 4 points may be
    * kept with rows padded to 4 floats inside the solver: cg_solver_plane() / cg_solver_buffer_len() do
    * not describe that internal layout, and x is only complete in the caller's array after
@@ -235,23 +246,32 @@ extern "C"
   void cg_solver_bind_partials_n(cg_solver *s, double *pAp_parts, double *rr_parts, int n);
 
   /* --- multi-GPU on RCCL (over xGMI inside a node): the halo exchange and the two dot-product
-   * all-reduces of the slab decomposition, issued by the library itself (no counterpart in the
+   * exchanges of the slab decomposition, issued by the library itself (no counterpart in the
    * reference, which is single-GPU).  One rank per GPU, rank r owns slab r along the slowest axis
    * (has_lo = r > 0, has_hi = r + 1 < world in its cg_solver_desc).  Rank 0 makes a unique id
    * (cg_rccl_unique_id) and hands the 128 bytes to the other ranks over any channel; every rank, with
    * its GPU current, creates its communicator (cg_rccl_comm_create, collective) -- or brings an
-   * ncclComm_t it already has -- and binds it (cg_solver_bind_rccl, collective).  From then on
-   * cg_solver_begin / cg_solver_iterate / cg_solver_finish run the multi-rank solve: per iteration
-   * kernel A, ncclAllReduce of the partials of p.Ap, kernel B, ncclAllReduce of the partials of r.r,
-   * grouped ncclSend / ncclRecv of r's boundary planes -- all on the solver's stream and replayed from
-   * one hipGraph, no host work inside the loop.  Every rank passes the same rel / lagged / iteration
-   * counts.  All four return an ncclResult_t value, 0 = success (a message goes to stderr otherwise);
-   * cg_solver_bind_rccl(s, NULL, 0, 1) unbinds. */
+   * ncclComm_t it already has -- and binds it (cg_solver_bind_rccl, collective; it splits a second
+   * communicator off for the boundary planes).  From then on cg_solver_begin / cg_solver_iterate /
+   * cg_solver_finish run the multi-rank solve: per iteration kernel A, ncclAllGather of one double per
+   * rank (its p.Ap), kernel B, ncclAllGather of r.r; beside kernel B, on a second stream, the boundary
+   * planes r will have after the iteration are computed ahead (cg_solver_edge_update) and travel by a
+   * grouped ncclSend / ncclRecv into the neighbours' ghost planes -- all replayed from one hipGraph, no
+   * host work inside the loop.  Every rank passes the same rel / lagged / iteration counts.  At most
+   * 1024 ranks.  All return an ncclResult_t value, 0 = success (a message goes to stderr otherwise);
+   * cg_solver_bind_rccl(s, NULL, 0, 1) unbinds.
+   * cg_solver_bind_rccl_peers names the ranks that own the slab below / above explicitly (-1: none; must
+   * agree with has_lo / has_hi) for rank layouts other than "slab r on rank r"; a rank may be its own
+   * neighbour on both sides (one rank, has_lo = has_hi = 1: every ghost plane receives the rank's own
+   * boundary plane on that side, which is how this path is tested on one GPU).
+   * cg_solver_rccl_ranks: the ranks of the bound communicator as RCCL counts them, 0 if none is bound. */
 #define CG_RCCL_ID_BYTES 128
   int cg_rccl_unique_id(unsigned char *id128);
   int cg_rccl_comm_create(const unsigned char *id128, int rank, int world, void **comm);
   int cg_rccl_comm_destroy(void *comm);
   int cg_solver_bind_rccl(cg_solver *s, void *comm, int rank, int world);
+  int cg_solver_bind_rccl_peers(cg_solver *s, void *comm, int rank, int world, int lo_rank, int hi_rank);
+  int cg_solver_rccl_ranks(cg_solver *s);
 
   /* --- direct xGMI path: slab neighbours write into each other's HBM, no collective library ---
    * (no counterpart in the reference, which is single-GPU).  Every rank allocates a box,

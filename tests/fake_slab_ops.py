@@ -122,6 +122,21 @@ class FakeSlabOps:
         ap = self._stencil(png)
         self.part[0] = float(np.sum(png[1:-1].astype(np.float64) * ap.astype(np.float64)))
 
+    # r's boundary planes ahead of kernel B (cg_solver_edge_copy / cg_solver_edge_update)
+    def edge_copy(self):
+        g, n, pl = self.ghost_offset, self.N, self.plane
+        self.edge_lo = self.r_buf[g:g + pl].clone()
+        self.edge_hi = self.r_buf[g + n - pl:g + n].clone()
+
+    def edge_update(self):
+        if not self.active:
+            return
+        k = self.it
+        alpha = np.float32(self.hist[k] / np.float32(self._dot(0)))
+        ap = self._stencil(self._ghosted(self.p_buf[(k & 1) ^ 1]))
+        self.edge_lo = torch.from_numpy(self._fma(-alpha, ap[0].reshape(-1), self.edge_lo.numpy()))
+        self.edge_hi = torch.from_numpy(self._fma(-alpha, ap[-1].reshape(-1), self.edge_hi.numpy()))
+
     def kernel_B(self):
         if not self.active:
             return
@@ -136,6 +151,9 @@ class FakeSlabOps:
         rg[1:-1] = self._fma(-alpha, ap, rg[1:-1])
         self.part[1] = float(np.sum(rg[1:-1].astype(np.float64) ** 2))
         self.it = k + 1
+        if hasattr(self, "edge_lo"):   # the planes computed ahead are what this kernel leaves in r
+            g, n, pl = self.ghost_offset, self.N, self.plane
+            assert torch.equal(self.edge_lo, self.r_buf[g:g + pl]) and torch.equal(self.edge_hi, self.r_buf[g + n - pl:g + n])
 
     def finish(self, hist_len=0):
         n = self.it

@@ -216,3 +216,34 @@ def test_benchmark_with_two_ranks_on_one_gpu_as_the_launcher_starts_it(tmp_path)
     assert out["config"]["comm"].startswith(("xgmi-links", "collectives")), out["config"]["comm"]
     assert out["value"] > 0 and np.isfinite(out["final_residue"])
     assert abs(out["value"] - 2 * out["iterations_per_sec_global"]) <= 1e-3 * out["value"]
+
+
+def test_benchmark_started_plainly_with_two_gpus_starts_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (the way the single-GPU benchmark is started) must
+    start the two rank processes itself and report n_gpus = 2 -- here with both ranks on this box's one GPU and
+    gloo instead of RCCL.  The default multi-rank workload: 8192 x 8192 per GPU as `value`, and the 1024 x 1024 x 128
+    slab of the 8-GPU configuration as `config3`, each with the same slab on one GPU beside it."""
+    import json
+    env = dict(os.environ, CG_BENCH_DEVICE="0")
+    for k in list(env):
+        if k.startswith("TORCHELASTIC_") or k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6",
+           "--warmup", "2", "--repeats", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "slab2" and out["scaling"] == "weak"
+    assert out["config"]["workload"] == "2d-8192" and out["config"]["global_extents"] == [8192, 16384]
+    assert out["value"] > 0 and out["single_gpu_reference"]["value"] > 0
+    assert 0 < out["roofline"]["frac"] <= 1 and 0 < out["hbm_frac_moved"] <= 1
+    c3 = out["config3"]
+    assert c3["config"]["local_extents"] == [1024, 1024, 128] and c3["config"]["global_extents"] == [1024, 1024, 256]
+    assert c3["value"] > 0 and c3["single_gpu_reference"]["value"] > 0
+    # a mismatch between --gpus and the ranks that exist is an error, never a silent single-GPU run
+    env1 = dict(env, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2"], env=env1,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

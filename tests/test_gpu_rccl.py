@@ -55,6 +55,73 @@ def test_one_rccl_rank_is_bit_identical_to_the_plain_solver(lib, ext):
     lib.rccl_comm_destroy(comm)
 
 
+def mirror_reference(lib, ext, b, plan):
+    """The step interface on a slab whose lower and upper neighbour are the slab itself: after every kernel B
+    (and at the start) the ghost planes of r receive r's own boundary plane of that side."""
+    from conjugate_gradient_amd.slab import HipSlabOps
+    N = int(np.prod(ext))
+    o = HipSlabOps(lib, ext, 1, 1, torch.device("cuda", 0))
+    x = torch.zeros(N, dtype=torch.float32, device="cuda")
+    g, pl = o.ghost_offset, o.plane
+
+    def mirror():
+        with o.stream_ctx():
+            o.r_buf[g - pl:g] = o.r_buf[g:g + pl]
+            o.r_buf[g + N:g + N + pl] = o.r_buf[g + N - pl:g + N]
+
+    with o.stream_ctx():
+        o.begin_local(b, x)
+        o.init_state(0.0, 1, 0)
+    mirror()
+    for n in plan:
+        with o.stream_ctx():
+            o.add_iterations(n)
+        for _ in range(n):
+            with o.stream_ctx():
+                o.kernel_A()
+                o.kernel_B()
+            mirror()
+    out = o.finish(hist_len=sum(plan))
+    torch.cuda.synchronize()
+    o.solver.close()
+    return x, out
+
+
+@pytest.mark.parametrize("ext", [[256, 256], [1024, 512], [64, 64, 16], [256, 64, 32], [1024, 256, 16], [32, 32, 32, 32], [16, 16, 16, 8, 8]])
+def test_ring_of_one_rank_runs_the_whole_multi_rank_machinery(lib, ext):
+    """One RCCL rank that is its own lower and upper neighbour (cg_solver_bind_rccl_peers with lo = hi = 0): the
+    all-gathers of the per-rank sums, the side stream, the boundary planes computed ahead of kernel B and the
+    grouped ncclSend / ncclRecv into the ghost planes all run as they do between GPUs -- from plain launches
+    and replayed from the captured graph -- and must reproduce the step interface with hand-copied planes bit
+    for bit."""
+    N = int(np.prod(ext))
+    b = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(b.data_ptr(), N, 13)
+    torch.cuda.synchronize()
+    plan = [3, 45, 2]                              # graphs of 20, tails of 3, 5 and 2
+    x0, out0 = mirror_reference(lib, ext, b, plan)
+
+    comm = lib.rccl_comm_create(lib.rccl_unique_id(), 0, 1)
+    s = lib.make_solver(ext, 0, 1, 1)
+    s.bind_rccl(comm, 0, 1, peers=(0, 0))
+    assert s.rccl_ranks() == 1
+    x1 = torch.zeros(N, dtype=torch.float32, device="cuda")
+    for use_graph in (True, False, True):
+        x1.zero_()
+        torch.cuda.synchronize()
+        s.begin(b.data_ptr(), x1.data_ptr(), 0.0, 1)
+        for n in plan:
+            s.iterate(n, use_graph=use_graph)
+        out1 = s.finish(hist_len=sum(plan))
+        assert out1 == out0, (use_graph, out1[0], out0[0])
+        assert torch.equal(x1, x0)
+    msA, msB = s.time_kernels(4)
+    assert msA > 0 and msB > 0
+    s.bind_rccl(None, 0, 1)
+    s.close()
+    lib.rccl_comm_destroy(comm)
+
+
 def test_slab_driver_over_rccl_world_1(tmp_path):
     """bench.py's multi-rank path with one rank over the nccl backend: SlabCG.enable_rccl() carries the
     unique id through torch.distributed, the timed loop runs from the library's graph."""

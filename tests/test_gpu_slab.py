@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def run_virtual(pkg, lib, L, d, nranks, b, iters, engine=0, heights=None):
+def run_virtual(pkg, lib, L, d, nranks, b, iters, engine=0, heights=None, ahead=False):
     from conjugate_gradient_amd.slab import HipSlabOps
     dev = torch.device("cuda", 0)
     heights = heights or [L // nranks] * nranks
@@ -44,18 +44,28 @@ def run_virtual(pkg, lib, L, d, nranks, b, iters, engine=0, heights=None):
             o.sum_tensor(which).copy_(tot)
         sync()
 
-    def exchange():
+    def exchange(from_edge=False):
+        """from_edge: the planes that travel are the ones computed ahead of kernel B (cg_solver_edge_*), which
+        must be the bits kernel B left in r's boundary planes."""
         sync()
         for r, o in enumerate(slabs):
             g, n, pl = o.ghost_offset, n_locs[r], o.plane
             if r > 0:
                 lo = slabs[r - 1]
                 glo, nlo = lo.ghost_offset, n_locs[r - 1]
-                o.r_buf[g - pl:g] = lo.r_buf[glo + nlo - pl:glo + nlo]
+                plane = lo.r_buf[glo + nlo - pl:glo + nlo]
+                if from_edge:
+                    assert torch.equal(lo.edge_hi, plane), f"rank {r - 1}: upper plane computed ahead differs from r"
+                    plane = lo.edge_hi
+                o.r_buf[g - pl:g] = plane
             if r < nranks - 1:
                 hi = slabs[r + 1]
                 ghi = hi.ghost_offset
-                o.r_buf[g + n:g + n + pl] = hi.r_buf[ghi:ghi + pl]
+                plane = hi.r_buf[ghi:ghi + pl]
+                if from_edge:
+                    assert torch.equal(hi.edge_lo, plane), f"rank {r + 1}: lower plane computed ahead differs from r"
+                    plane = hi.edge_lo
+                o.r_buf[g + n:g + n + pl] = plane
         sync()
 
     for o, bb, xx in zip(slabs, bs, xs):
@@ -68,12 +78,16 @@ def run_virtual(pkg, lib, L, d, nranks, b, iters, engine=0, heights=None):
         o.add_iterations(iters)
     for _ in range(iters):
         for o in slabs:
+            if ahead:
+                o.edge_copy()
             o.kernel_A()
         allreduce(0)
         for o in slabs:
+            if ahead:
+                o.edge_update()
             o.kernel_B()
         allreduce(1)
-        exchange()
+        exchange(ahead)
     outs = [o.finish(hist_len=iters) for o in slabs]
     sync()
     x = torch.cat(xs).cpu().numpy()
@@ -100,6 +114,24 @@ def test_virtual_ranks_match_single_gpu_and_oracle(pkg, lib, oracle, engine_env,
     assert np.linalg.norm(x - x1.cpu().numpy()) <= 1e-5 * np.linalg.norm(xe)
     n = min(len(hist), len(h1), 8)
     assert np.allclose(hist[:n], h1[:n], rtol=1e-5)
+
+
+@pytest.mark.parametrize("L,d,nranks", [(64, 2, 4), (16, 3, 2), (10, 2, 2), (6, 3, 3), (8, 4, 2), (32, 3, 2), (16, 4, 2), (256, 3, 4),
+                                        (1024, 2, 2), (16, 5, 2)])
+def test_boundary_planes_computed_ahead_of_kernel_B_are_its_bits(pkg, lib, engine_env, L, d, nranks):
+    """cg_solver_edge_copy + cg_solver_edge_update produce, before kernel B runs, the two boundary planes of r
+    that kernel B then writes -- bit for bit on every rank and in every iteration (run_virtual compares them
+    after each kernel B and hands them to the neighbours instead of r's own planes), so the solve is the
+    same solve: same history, same x as with r's planes."""
+    N = L ** d
+    bd = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(bd.data_ptr(), N, 21)
+    b = bd.cpu().numpy()
+    iters = 12 if N > (1 << 22) else 40
+    x0, it0, h0 = run_virtual(pkg, lib, L, d, nranks, b, iters)
+    x1, it1, h1 = run_virtual(pkg, lib, L, d, nranks, b, iters, ahead=True)
+    assert it0 == it1 and h0 == h1
+    assert np.array_equal(x0, x1)
 
 
 @pytest.mark.parametrize("L,d,heights", [(16, 3, [6, 10]), (64, 2, [10, 30, 24]), (32, 3, [4, 20, 8])])

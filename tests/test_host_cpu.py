@@ -124,24 +124,47 @@ def _bench_module():
 
 
 def test_bench_prices_bytes_as_documented():
-    """effective = the 44 B of the specified three-kernel fusion (A 20, B 24), whatever the kernels move;
-    moved = 32 B (A 12, B 20), or 30 B (B 18 on average) when x is updated every second iteration."""
+    """roofline.achieved / frac are priced with the bytes the kernels stream: 32 B per point and iteration
+    (A 12, B 20), or 30 B (B 18 on average) when x is updated every second iteration.  The 44 B of the
+    three-kernel fusion appear only as an equivalent rate, never as a fraction of the peak."""
     bench = _bench_module()
     N = 1 << 26
     run = {"N": N, "msA": 0.128, "msB": 0.184, "kernel": "k_rows", "paired_x": True}
     roof = bench.roofline_of(run, {"A": 800_000_000, "B": 1_200_000_000}, "note", {})
     assert roof["kernel"] == "k_rows<MODE_B>" and roof["bound"] == "hbm" and roof["unit"] == "GB/s"
-    assert roof["algorithmic_bytes"] == 24 * N and roof["moved_bytes_per_point"] == 18
-    assert abs(roof["achieved"] - 24 * N / 0.184e-3 / 1e9) < 0.1
-    assert abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-4 and roof["frac"] == roof["frac_effective"]
-    assert abs(roof["achieved_moved"] - 18 * N / 0.184e-3 / 1e9) < 0.1
-    assert "effective" in roof["pricing"] and "18 B/point" in roof["pricing"]
-    assert roof["traffic"] == 1_200_000_000 and abs(roof["traffic_over_moved"] - 1.2e9 / (18 * N)) < 1e-3
-    assert abs(roof["other_kernel"]["achieved_moved"] - 12 * N / 0.128e-3 / 1e9) < 0.1
+    assert roof["algorithmic_bytes"] == 18 * N and roof["algorithmic_bytes_per_point"] == 18
+    assert abs(roof["achieved"] - 18 * N / 0.184e-3 / 1e9) < 0.1
+    assert abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-4 and roof["frac"] <= 1.0
+    assert abs(roof["three_kernel_equivalent_GBps"] - 24 * N / 0.184e-3 / 1e9) < 0.1
+    assert "18 B/point" in roof["pricing"]
+    assert roof["traffic"] == 1_200_000_000 and abs(roof["traffic_over_algorithmic"] - 1.2e9 / (18 * N)) < 1e-3
+    # frac x peak x launch time gives the algorithmic bytes back, which the counter traffic is compared with
+    assert abs(roof["frac"] * 8000e9 * roof["ms_per_launch"] * 1e-3 - roof["algorithmic_bytes"]) < 1e-3 * roof["algorithmic_bytes"]
+    assert abs(roof["other_kernel"]["achieved"] - 12 * N / 0.128e-3 / 1e9) < 0.1 and roof["other_kernel"]["frac"] <= 1.0
     run["paired_x"] = False
-    assert bench.roofline_of(run)["moved_bytes_per_point"] == 20
+    assert bench.roofline_of(run)["algorithmic_bytes_per_point"] == 20
     its = 3000.0
     paired, plain = bench.iteration_rates(N, its, True), bench.iteration_rates(N, its, False)
     assert abs(paired["hbm_moved_GBps"] - 30 * N * its / 1e9) < 0.1 and abs(plain["hbm_moved_GBps"] - 32 * N * its / 1e9) < 0.1
-    assert paired["hbm_effective_GBps"] == plain["hbm_effective_GBps"]
-    assert abs(paired["hbm_frac_effective"] - 44 * N * its / 8e12) < 1e-4
+    assert paired["three_kernel_equivalent_GBps"] == plain["three_kernel_equivalent_GBps"]
+    assert abs(paired["hbm_frac_moved"] - 30 * N * its / 8e12) < 1e-4 and paired["hbm_frac_moved"] <= 1.0
+
+    def fracs(o):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if "frac" in k and isinstance(v, (int, float)):
+                    yield k, v
+                yield from fracs(v)
+    for o in (roof, paired, plain):
+        assert all(v <= 1.0 for _, v in fracs(o)), list(fracs(o))
+
+
+def test_bench_refuses_a_rank_count_that_does_not_match(tmp_path):
+    """--gpus N with a different WORLD_SIZE is an error before anything touches a GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
