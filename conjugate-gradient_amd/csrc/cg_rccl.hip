@@ -18,6 +18,7 @@
 // The reference has no multi-GPU code; its loop (conjugate-gradient_gpu.cu:349-370) is what every rank runs.
 #include <rccl/rccl.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -84,6 +85,7 @@ int Solver::bind_rccl(void *comm, int rank, int world, int lo_rank, int hi_rank)
     CHECK(hipStreamSynchronize(side_));
   if (!comm)
   {
+    drop_graphs(); // RCCL keeps a communicator alive while a graph that holds its operations exists
     rccl_release();
     rccl_ = false;
     comm_ = nullptr;
@@ -116,9 +118,11 @@ int Solver::bind_rccl(void *comm, int rank, int world, int lo_rank, int hi_rank)
   ensure_side();
   // the plane exchange runs beside the dot-product exchanges: a communicator of its own keeps the two
   // independent (collective; if RCCL cannot split, the planes share comm and RCCL orders them itself)
+  drop_graphs();
   rccl_release();
   ncclComm_t halo = nullptr;
-  const ncclResult_t sp = ncclCommSplit(c, 0, rank, &halo, nullptr);
+  const char *shared = getenv("CG_RCCL_SHARED_COMM"); // 1: no second communicator (every rank alike)
+  const ncclResult_t sp = (shared && *shared == '1') ? ncclInvalidUsage : ncclCommSplit(c, 0, rank, &halo, nullptr);
   if (sp == ncclSuccess && halo)
   {
     comm_halo_ = halo;
@@ -126,7 +130,8 @@ int Solver::bind_rccl(void *comm, int rank, int world, int lo_rank, int hi_rank)
   }
   else
   {
-    fprintf(stderr, "RCCL: ncclCommSplit failed (%s); boundary planes share the communicator\n", ncclGetErrorString(sp));
+    if (!(shared && *shared == '1'))
+      fprintf(stderr, "RCCL: ncclCommSplit failed (%s); boundary planes share the communicator\n", ncclGetErrorString(sp));
     comm_halo_ = comm;
   }
   comm_ = comm;

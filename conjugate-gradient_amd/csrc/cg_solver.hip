@@ -646,7 +646,7 @@ Solver::~Solver()
     (void)hipFree(rank_sums_);
   if (edge_)
     (void)hipFree(edge_);
-  for (hipEvent_t e : {ev_fork_, ev_copy_, ev_alpha_, ev_join_})
+  for (hipEvent_t e : {ev_fork_, ev_copy_, ev_alpha_, ev_join_, ev_cap_begin_, ev_cap_end_})
     if (e)
       (void)hipEventDestroy(e);
   if (side_)
@@ -1327,7 +1327,7 @@ void Solver::ensure_side()
   if (side_)
     return;
   CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
-  for (hipEvent_t *e : {&ev_fork_, &ev_copy_, &ev_alpha_, &ev_join_})
+  for (hipEvent_t *e : {&ev_fork_, &ev_copy_, &ev_alpha_, &ev_join_, &ev_cap_begin_, &ev_cap_end_})
     CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
 }
 
@@ -1557,8 +1557,27 @@ void Solver::iterate(int n, bool use_graph)
     hipGraph_t g;
     hipGraphExec_t ge;
     CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    // With boundary planes travelling on the second stream the two streams trade places for the capture: the
+    // stream the capture starts on takes the plane work and the forked one the kernels and all-gathers.  (A
+    // grouped ncclSend / ncclRecv captured on a forked stream sends the HIP runtime into an endless recursion
+    // when the graph is built -- RCCL 2.26 / ROCm 7.0 -- while on the capture's own stream it is fine, and so
+    // are collectives on a forked stream.)  A graph is a DAG either way: replay does not care which stream a
+    // node was recorded on.
+    const bool halo = rccl_ && (desc_.has_lo || desc_.has_hi);
+    if (halo)
+    {
+      CHECK(hipEventRecord(ev_cap_begin_, stream_));
+      CHECK(hipStreamWaitEvent(side_, ev_cap_begin_, 0));
+      std::swap(stream_, side_);
+    }
     for (int i = 0; i < iters; i++)
       launch_iteration();
+    if (halo)
+    {
+      std::swap(stream_, side_);
+      CHECK(hipEventRecord(ev_cap_end_, side_)); // the kernels' stream during the capture
+      CHECK(hipStreamWaitEvent(stream_, ev_cap_end_, 0));
+    }
     CHECK(hipStreamEndCapture(stream_, &g));
     CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     CHECK(hipGraphDestroy(g));

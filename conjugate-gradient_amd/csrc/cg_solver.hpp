@@ -193,6 +193,7 @@ private:
   // second stream and the events that tie it to stream_ (also inside a capture)
   hipStream_t side_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_copy_ = nullptr, ev_alpha_ = nullptr, ev_join_ = nullptr;
+  hipEvent_t ev_cap_begin_ = nullptr, ev_cap_end_ = nullptr; // fork / join of the second stream around a capture
   void ensure_side();
   float *edge_ = nullptr;    // [2][edge_pad_]
   size_t edge_pad_ = 0;

@@ -63,6 +63,10 @@ class HipSlabOps:
         self.blocks = self.solver.blocks     # partial sums this rank's kernels write (the larger of A's and B's)
         self.blocks_of = [self.solver.blocks_of(0), self.solver.blocks_of(1)]
         self.nparts = self.blocks            # ... and the number every rank reduces
+        # the planes r's boundary will hold after the coming kernel B, computed ahead of it by the library
+        # (cg_solver_edge_copy / cg_solver_edge_update): library memory, viewed as tensors for the collectives
+        self.edge_lo = self._view(self.solver.edge_plane(0), self.plane) if has_lo else None
+        self.edge_hi = self._view(self.solver.edge_plane(1), self.plane) if has_hi else None
 
     def set_nparts(self, n):
         """Ranks whose slabs differ in shape own different numbers of workgroups; all of them reduce
@@ -76,11 +80,6 @@ class HipSlabOps:
         self.parts.zero_()
         torch.cuda.synchronize(self.device)
         self.solver.bind_partials(self.parts[0].data_ptr(), self.parts[1].data_ptr(), self.nparts)
-
-        # the planes r's boundary will hold after the coming kernel B, computed ahead of it by the library
-        # (cg_solver_edge_copy / cg_solver_edge_update): library memory, viewed as tensors for the collectives
-        self.edge_lo = self._view(self.solver.edge_plane(0), self.plane) if has_lo else None
-        self.edge_hi = self._view(self.solver.edge_plane(1), self.plane) if has_hi else None
 
     def _view(self, ptr, n):
         class Raw:
