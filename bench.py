@@ -91,7 +91,8 @@ def parse():
                     help="multi-rank runs: skip the second workload (1024 x 1024 x 128 per GPU, the 8-GPU configuration's slab)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps iterations; the median is reported")
+    ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps iterations; the median is reported "
+                    "(the first region of a run also captures the iteration graph, and the clocks settle during the first few)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--no-beyond-cache", action="store_true",
                     help="skip the second, larger 2-D workload whose vectors exceed the Infinity Cache")

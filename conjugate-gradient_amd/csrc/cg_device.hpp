@@ -16,11 +16,13 @@
 // other workgroups.
 //
 // Paired x update: both p buffers are intact while kernel B runs, so x need not be touched
-// every iteration.  Kernel B of an even iteration k skips x (3 words), kernel B of
-// iteration k+1 reads both p and applies x = fma(alpha_k, p_k, x), x = fma(alpha_k+1,
-// p_k+1, x) in that order (6 words): the bits of two single updates, 4.5 instead of 5
-// words per iteration on average.  Whenever the host gets control back with an update
-// pending (odd count, stop by the tolerance), a flush launch applies it (CgState::xdef_k).
+// every iteration.  Of two consecutive launches of kernel B the first skips x (3 words), the
+// second reads both p and applies x = fma(alpha_k, p_k, x), x = fma(alpha_k+1, p_k+1, x) in
+// that order (6 words): the bits of two single updates, 4.5 instead of 5 words per iteration
+// on average.  The host pairs the launches of one request (the last launch of a request
+// never skips), so an update can only be left pending by a stop on the tolerance between the
+// two launches of a pair; a flush launch applies it whenever the host gets control back
+// (CgState::xdef_k).
 //
 // alpha, beta, the iteration counter and the stop test live on the device
 // (CgState).  Dot products are deterministic: every workgroup writes one double
@@ -81,10 +83,11 @@ struct CgState
   float reltol;
   float alpha, beta;
   float pAp;
-  // Paired x update: kernel B of an even iteration k may leave out x += alpha_k p_k (no read, no write of x)
-  // and record xdef_k = k; kernel B of iteration k + 1 then applies both updates, in order, from the two p
-  // buffers.  A flush launch applies a pending update where the host needs x and records the iteration
-  // count it did so at.  Kernel B of iteration k reads alpha_hist[(k - 1) & 1] and writes alpha_hist[k & 1].
+  // Paired x update: a kernel B launched with VecArgs::xdefer leaves out x += alpha_k p_k (no read, no write
+  // of x) and records xdef_k = k; kernel B of iteration k + 1 (launched without xdefer: the host never sets it
+  // twice in a row) then applies both updates, in order, from the two p buffers.  A flush launch applies a
+  // pending update where the host needs x and records the iteration count it did so at.  Kernel B of
+  // iteration k reads alpha_hist[(k - 1) & 1] and writes alpha_hist[k & 1].
   int xdef_k;       // last iteration whose x update was left out (-2: none)
   int xflushed_at;  // iteration count at which a flush applied a pending update (-1: never)
   float alpha_hist[2];
@@ -112,7 +115,7 @@ struct VecArgs
   float *push_lo, *push_hi;
   const unsigned long long *push_seq;
   unsigned long long push_stride;
-  int xdefer; // kernel B may leave x alone on even iterations (see CgState::xdef_k)
+  int xdefer; // this kernel B leaves x alone; the next one applies both updates (see CgState::xdef_k)
   // RCCL path: the last workgroup of the launch to finish also adds all of the launch's partials up (fixed
   // order) into rank_sum[0], so that one double per rank travels; ticket counts the finished workgroups
   // (device memory, zero between launches).  Null: nobody does.
@@ -340,17 +343,14 @@ __device__ __forceinline__ IterCtl prologue_B(const VecArgs &a, double *sh)
   c.alpha_prev = 0.0f;
   if constexpr (XD)
   {
-    // odd iterations only read xdef_k, even ones only write it
-    if (c.k & 1)
-    {
-      if (st->xdef_k == c.k - 1 && st->xflushed_at != c.k)
-      {
-        c.xm = 2;
-        c.alpha_prev = st->alpha_hist[0];
-      }
-    }
-    else if (a.xdefer)
+    // a launch that may leave x alone only writes xdef_k, every other launch only reads it
+    if (a.xdefer)
       c.xm = 1;
+    else if (st->xdef_k == c.k - 1 && st->xflushed_at != c.k)
+    {
+      c.xm = 2;
+      c.alpha_prev = st->alpha_hist[(c.k - 1) & 1];
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {

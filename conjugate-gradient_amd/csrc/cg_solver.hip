@@ -103,14 +103,16 @@ __global__ void __launch_bounds__(64) k_init_state(CgState *st, const double *__
 
 // Paired x update (CgState::xdef_k): applies the update the last kernel B left out, if any.  The decision
 // is read from words no workgroup of this launch writes; k_flush_mark records it afterwards.
-// p: the buffer kernel B of an even iteration reads (p1); alpha_hist[0] is that iteration's alpha.
+// The pending update belongs to iteration j = itA - 1: its p is the buffer kernel B of iteration j read.
 __global__ void __launch_bounds__(256) k_flush_x(const CgState *__restrict__ st, float *__restrict__ x,
-                                                 const float *__restrict__ p, unsigned long long n, int vec4)
+                                                 const float *__restrict__ p0, const float *__restrict__ p1,
+                                                 unsigned long long n, int vec4)
 {
-  const int it = st->itA;
-  if (!(it & 1) || st->xdef_k != it - 1 || st->xflushed_at == it)
+  const int it = st->itA, j = it - 1;
+  if (st->xdef_k != j || st->xflushed_at == it)
     return;
-  const float alpha = st->alpha_hist[0];
+  const float alpha = st->alpha_hist[j & 1];
+  const float *__restrict__ p = (j & 1) ? p0 : p1;
   const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
   const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (vec4)
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(256) k_flush_x(const CgState *__restrict__ st,
 __global__ void __launch_bounds__(64) k_flush_mark(CgState *st)
 {
   const int it = st->itA;
-  if (threadIdx.x == 0 && (it & 1) && st->xdef_k == it - 1)
+  if (threadIdx.x == 0 && st->xdef_k == it - 1)
     st->xflushed_at = it;
 }
 
@@ -1052,9 +1054,10 @@ void Solver::flush_x()
   if (!xdefer_ || !may_be_pending_)
     return;
   may_be_pending_ = false;
-  const int vec4 = (((uintptr_t)x_ | (uintptr_t)p1_) % 16 == 0) ? 1 : 0;
+  last_deferred_ = false;
+  const int vec4 = (((uintptr_t)x_ | (uintptr_t)p0_ | (uintptr_t)p1_) % 16 == 0) ? 1 : 0;
   const int grid = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((Np_ / 4 + 255) / 256, 4096));
-  hipLaunchKernelGGL(k_flush_x, dim3(grid), dim3(256), 0, stream_, st_, x_, p1_, (unsigned long long)Np_, vec4);
+  hipLaunchKernelGGL(k_flush_x, dim3(grid), dim3(256), 0, stream_, st_, x_, p0_, p1_, (unsigned long long)Np_, vec4);
   hipLaunchKernelGGL(k_flush_mark, dim3(1), dim3(64), 0, stream_, st_);
   CHECK(hipGetLastError());
 }
@@ -1063,7 +1066,9 @@ void Solver::launch_B(bool may_defer)
 {
   VecArgs a = args();
   a.part_out = partB_;
-  a.xdefer = (xdefer_ && may_defer) ? 1 : 0;
+  // never two launches in a row that leave x alone: the second would lose the first one's update
+  a.xdefer = (xdefer_ && may_defer && !last_deferred_) ? 1 : 0;
+  last_deferred_ = a.xdefer != 0;
   if (a.xdefer)
     may_be_pending_ = true;
   if (rccl_)
@@ -1459,7 +1464,7 @@ void Solver::links_times(float *ms_xA, float *ms_xB) const
     *ms_xB = ms_xB_;
 }
 
-void Solver::launch_iteration(hipEvent_t *ev)
+void Solver::launch_iteration(bool may_defer, hipEvent_t *ev)
 {
   // with a communicator bound and slab neighbours, r's boundary planes travel on the side stream while kernel
   // B runs: [side] copy of the planes (beside kernel A) -> [after the p.Ap exchange] edge_update -> send / recv
@@ -1492,7 +1497,7 @@ void Solver::launch_iteration(hipEvent_t *ev)
     CHECK(hipEventRecord(ev_join_, side_));
     CHECK(hipStreamWaitEvent(stream_, ev_copy_, 0)); // kernel B overwrites what the copy reads
   }
-  launch_B();
+  launch_B(may_defer);
   if (ev)
     CHECK(hipEventRecord(ev[3], stream_));
   if (linked_)
@@ -1546,7 +1551,7 @@ void Solver::iterate(int n, bool use_graph)
   if (!use_graph)
   {
     for (int i = 0; i < n; i++)
-      launch_iteration();
+      launch_iteration(i + 1 < n); // the launches of one request pair up; the last one never leaves x alone
     flush_x();
     return;
   }
@@ -1570,8 +1575,10 @@ void Solver::iterate(int n, bool use_graph)
       CHECK(hipStreamWaitEvent(side_, ev_cap_begin_, 0));
       std::swap(stream_, side_);
     }
+    last_deferred_ = false; // every graph pairs its own launches and ends with x complete (unless a stop falls inside a pair)
     for (int i = 0; i < iters; i++)
-      launch_iteration();
+      launch_iteration(i + 1 < iters);
+    last_deferred_ = false;
     if (halo)
     {
       std::swap(stream_, side_);
@@ -1684,7 +1691,7 @@ void Solver::time_kernels(int n, float *ms_A, float *ms_B)
     CHECK(hipEventCreate(&e));
   add_iterations(n);
   for (int i = 0; i < n; i++)
-    launch_iteration(&ev[5 * (size_t)i]);
+    launch_iteration(i + 1 < n, &ev[5 * (size_t)i]);
   flush_x();
   CHECK(hipStreamSynchronize(stream_));
   double t[4] = {0, 0, 0, 0};

@@ -87,7 +87,7 @@ public:
   void init_state(double rel, int lagged, int maxit);         // from the bound r.r sum
   void add_iterations(int n);                                 // maxit = it + n
   void launch_A();
-  // may_defer: this launch may leave x alone (even iterations); the caller then ends with flush_x()
+  // may_defer: this launch may leave x alone (it does unless the previous launch did); the caller ends with flush_x()
   void launch_B(bool may_defer = true);
   void flush_x();
   void launch_stencil(const float *u, float *out, bool ghost); // out = A u with this geometry
@@ -131,7 +131,7 @@ private:
   void build_geometry();
   // A, B and, with boxes or a communicator bound, the exchanges; ev (5 events, may be null) are recorded
   // before A, after A, after A's exchange, after B, after B's exchange
-  void launch_iteration(hipEvent_t *ev = nullptr);
+  void launch_iteration(bool may_defer = true, hipEvent_t *ev = nullptr);
   void launch_mode(int mode, bool ghost, const VecArgs &a);
   VecArgs args() const;
 
@@ -150,6 +150,7 @@ private:
   int engine_ = ENGINE_SCALAR;
   int policy_ = POL_KEEP_R;
   bool xdefer_ = false; // kernel B of this solver's engine implements the paired x update
+  bool last_deferred_ = false;  // the last kernel B enqueued left x alone: the next one must not
   bool may_be_pending_ = false; // a kernel B that may have left x alone was enqueued since the last flush_x()
   int layout_ = LAYOUT_LEX;
   RowsGeom rg_{}, rgA_{};     // kernel B (and the plain stencil) / kernel A
