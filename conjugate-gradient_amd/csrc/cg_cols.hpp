@@ -37,10 +37,16 @@ namespace cgamd
 // Exact rows (g.xl, both kernels through LDS): a row whose n0/4 lanes are not a power of two would idle up
 // to half of its slot; instead it takes exactly n0/4 lanes, rows cross wave boundaries, and the x
 // neighbours of a lane come from LDS as well instead of from lane shifts.
-template <int MODE, bool GHOST, int D, int R, bool STREAM, bool LDS>
-__global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LDS) ? 4 : 1) k_cols(const RowsGeom g, const VecArgs a)
+// TILE (4-D through LDS only): the column slots of a workgroup form a patch of axis 1 x blocks of axis d-2
+// (g.cpg / g.t2 by g.t2 slots) instead of a strip along axis 1, so that block-edge neighbours along axis d-2
+// inside the patch are rows of this workgroup as well.
+// TILE = 2: the same in workgroups of up to 1024 lanes (twice the slots).
+template <int MODE, bool GHOST, int D, int R, bool STREAM, bool LDS, int TILE = 0>
+__global__ void __launch_bounds__(TILE == 2 ? 1024 : 512, (MODE == MODE_A && D == 4 && STREAM && LDS) ? 4 : 1) k_cols(const RowsGeom g, const VecArgs a)
 {
-  __shared__ float4 hand[LDS ? 2 * R * 512 : 1];
+  static_assert(!TILE || (D == 4 && LDS), "tiled slots exist in 4-D with the LDS hand-off only");
+  constexpr int BLK = TILE == 2 ? 1024 : 512; // lanes a workgroup can have: the LDS hand-off's row pitch
+  __shared__ float4 hand[LDS ? 2 * R * BLK : 1];
   static_assert(D == 3 || D == 4 || D == 5, "columns in blocks: d = 3, 4 and 5");
   static_assert(R == 1 || R == 2, "columns per lane");
   __shared__ double sh[16];
@@ -99,29 +105,63 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
     const unsigned seg = item % g.bpc;
     const unsigned col = item / g.bpc;
     const unsigned cs = (unsigned)tid / g.sub; // column slot within the workgroup
-    const unsigned c = col * g.cpg + cs;
     const unsigned x0 = ((unsigned)tid % g.sub) * 4u;
     // a row holds n0/4 lanes rounded up to a power of two; idle lanes (past the end of the row, past
     // the last column) shadow a valid quad and store nothing
     // (exact rows, g.xl: a row takes exactly n0/4 lanes and the lanes left over at the end of the
     // workgroup form no slot)
     const bool slot = cs < g.cpg;
-    const bool act = slot && c < g.ncols && x0 < g.n0;
-    unsigned hi = (slot && c < g.ncols) ? c : g.ncols - 1u;
     long long base = x0 < g.n0 ? x0 : ((g.n0 + 3u) & ~3u) - 4u;
     unsigned okm = 0, okp = 0;
-#pragma unroll
-    for (int k = 0; k < NA; k++)
+    unsigned hi;
+    bool valid;
+    // tiled slots (4-D through LDS, g.t2 > 1): the slots of a workgroup form a t1 x t2 patch of axis 1 x blocks
+    // of axis d-2 instead of a strip along axis 1, so that block-edge neighbours along axis d-2 are rows of
+    // this workgroup as well; s2 = the slot's position along that axis
+    unsigned t1 = g.cpg, s2 = 0;
+    if constexpr (TILE)
     {
-      const unsigned nk = g.nk[k];
-      const unsigned ck = hi % nk;
-      hi /= nk;
-      base += (long long)ck * (long long)g.sk[k];
+      t1 = g.cpg / g.t2;
+      const unsigned nt1 = (g.nk[0] + t1 - 1) / t1;
+      // workgroups b, b + 8, ... run on one XCD (round-robin dispatch) and share its L2: with g.xcd set, the
+      // patches of one XCD are g.xcd neighbours along axis 1 (and all of axis d-2) instead of every eighth
+      unsigned cc = col;
+      if (g.xcd)
+      {
+        const unsigned x = col % 8u, q = col / 8u;
+        cc = (q / g.xcd) * nt1 + x * g.xcd + q % g.xcd;
+      }
+      const unsigned c1 = (cc % nt1) * t1 + cs % t1;
+      s2 = cs / t1;
+      const unsigned blk = (cc / nt1) * g.t2 + s2, nblk = g.nb / (unsigned)R;
+      valid = slot && c1 < g.nk[0] && blk < nblk;
+      const unsigned ck = c1 < g.nk[0] ? c1 : g.nk[0] - 1u;
+      hi = blk < nblk ? blk : nblk - 1u;
+      base += (long long)ck * (long long)g.sk[0];
       if (ck > 0)
-        okm |= 1u << k;
-      if (ck + 1 < nk)
-        okp |= 1u << k;
+        okm |= 1u;
+      if (ck + 1 < g.nk[0])
+        okp |= 1u;
     }
+    else
+    {
+      const unsigned c = col * g.cpg + cs;
+      valid = slot && c < g.ncols;
+      hi = valid ? c : g.ncols - 1u;
+#pragma unroll
+      for (int k = 0; k < NA; k++)
+      {
+        const unsigned nk = g.nk[k];
+        const unsigned ck = hi % nk;
+        hi /= nk;
+        base += (long long)ck * (long long)g.sk[k];
+        if (ck > 0)
+          okm |= 1u << k;
+        if (ck + 1 < nk)
+          okp |= 1u << k;
+      }
+    }
+    const bool act = valid && x0 < g.n0;
     const unsigned cb = hi * (unsigned)R; // first coordinate of the lane's block along axis d-2
     base += (long long)cb * sb;
     const bool has_bm = cb > 0, has_bp = cb + R < g.nb;
@@ -133,7 +173,10 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
     // axis 1 (g.nk[0]; in 3-D the blocked axis itself): the neighbour is the next slot of this workgroup
     // unless the slot is the first / last one; it exists at all (okm / okp, has_bm / has_bp) only on the
     // same line of axis 1, where slot +-1 is column (block) +-1
-    const bool lds_m = LDS && cs > 0, lds_p = LDS && cs + 1 < g.cpg;
+    const unsigned s1 = TILE ? cs % t1 : cs; // the slot's position along axis 1
+    const bool lds_m = LDS && s1 > 0, lds_p = LDS && s1 + 1 < t1;
+    // tiled slots: the block below / above along axis d-2 is the slot t1 places down / up
+    const bool lds_bm = TILE && s2 > 0, lds_bp = TILE && s2 + 1 < g.t2;
     if constexpr (LDS)
       __syncthreads(); // the previous item's last step may still be read
 
@@ -161,6 +204,15 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
         if (has_bm && !lds_m)
           nb.bm = src.ld4(i - sb);
         if (has_bp && !lds_p)
+          nb.bp = src.ld4(i + R * sb);
+      }
+      else if constexpr (TILE)
+      {
+        nb.bm = zero4;
+        nb.bp = zero4;
+        if (has_bm && !lds_bm)
+          nb.bm = src.ld4(i - sb);
+        if (has_bp && !lds_bp)
           nb.bp = src.ld4(i + R * sb);
       }
       else
@@ -197,6 +249,38 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
       return nb;
     };
 
+    // Tiled slots: a lane loads at most one block-edge row (the patch's first slots along axis d-2 the row
+    // below their block, the last slots the row above) and at most R axis-1 neighbours (the first slots of the
+    // patch along axis 1 the rows below, the last the rows above); everything else comes from LDS.  Half the
+    // registers of Nb per row in flight, which is what lets kernel A keep the deep pipeline (neighbours of row
+    // y + 2 fetched in the very step in which their owners prefetch that row, while both are in L2) at two
+    // workgroups per CU.
+    struct NbT
+    {
+      float4 bx;
+      float4 ux[R];
+    };
+    const bool bx_on = TILE && ((s2 == 0 && has_bm) || (s2 + 1 == g.t2 && s2 != 0 && has_bp));
+    const long long bx_off = (TILE && s2 == 0) ? -sb : (long long)R * sb;
+    const bool ux_lo = TILE && s1 == 0; // this lane's loaded axis-1 neighbours are the rows below
+    const bool ux_on = TILE && (ux_lo ? (okm & 1u) != 0 : (s1 + 1 == t1 && (okp & 1u) != 0));
+    const long long ux_off = ux_lo ? -(long long)g.sk[0] : (long long)g.sk[0];
+    auto ldnbT = [&](long long yy) -> NbT {
+      NbT nb;
+      const long long i = base + (yy < y1 ? yy : y1 - 1) * rs;
+      nb.bx = zero4;
+      if (bx_on)
+        nb.bx = src.ld4(i + bx_off);
+#pragma unroll
+      for (int j = 0; j < R; j++)
+      {
+        nb.ux[j] = zero4;
+        if (ux_on)
+          nb.ux[j] = src.ld4(i + j * sb + ux_off);
+      }
+      return nb;
+    };
+
     float4 pm[R], pc[R], pn[R], xv[R], rv[R], qv[R];
 #pragma unroll
     for (int j = 0; j < R; j++)
@@ -227,8 +311,19 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
     // VGPRs and left one 512-lane workgroup per CU; the shallow one fits 128 (two workgroups per CU, as the
     // launch bounds above demand: 8 bytes of spills per lane).  128^4: kernel A 744 -> 665 us, 96^4 317 -> 248,
     // 64^3 x 512 360 -> 340; 3-D and 5-D grids and grids the caches hold lose a few percent and keep the deep one.
-    constexpr bool SHALLOW = (MODE == MODE_A) && D == 4 && STREAM;
-    Nb nb0 = ldnb(y0), nb1 = SHALLOW ? nb0 : ldnb(y0 + 1);
+    constexpr bool SHALLOW = (MODE == MODE_A) && D == 4 && STREAM && !TILE;
+    Nb nb0, nb1;
+    NbT t0, t1r;
+    if constexpr (TILE)
+    {
+      t0 = ldnbT(y0);
+      t1r = ldnbT(y0 + 1);
+    }
+    else
+    {
+      nb0 = ldnb(y0);
+      nb1 = SHALLOW ? nb0 : ldnb(y0 + 1);
+    }
 
     for (long long y = y0; y < y1; y++)
     {
@@ -255,14 +350,30 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
           }
         }
       }
-      const Nb nb2 = ldnb(SHALLOW ? y + 1 : y + 2);
+      Nb nb2;
+      NbT t2r;
+      if constexpr (TILE)
+      {
+        t2r = ldnbT(y + 2);
+        // the neighbours of this row that came from memory; LDS supplies the others below
+        nb0.bm = (s2 == 0) ? t0.bx : zero4;
+        nb0.bp = (s2 == 0) ? zero4 : t0.bx;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+        {
+          nb0.um[j] = ux_lo ? t0.ux[j] : zero4;
+          nb0.up[j] = ux_lo ? zero4 : t0.ux[j];
+        }
+      }
+      else
+        nb2 = ldnb(SHALLOW ? y + 1 : y + 2);
       float4 bm = nb0.bm, bp = nb0.bp;
       if constexpr (LDS)
       {
-        float4 *mine = hand + (size_t)(y & 1) * R * 512 + tid;
+        float4 *mine = hand + (size_t)(y & 1) * R * BLK + tid;
 #pragma unroll
         for (int j = 0; j < R; j++)
-          mine[j * 512] = pc[j];
+          mine[j * BLK] = pc[j];
         __syncthreads();
         if constexpr (NA > 0)
         {
@@ -270,15 +381,22 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
           for (int j = 0; j < R; j++)
           {
             if (lds_p && (okp & 1u))
-              nb0.up[j] = mine[j * 512 + (int)g.sub];
+              nb0.up[j] = mine[j * BLK + (int)g.sub];
             if (lds_m && (okm & 1u))
-              nb0.um[j] = mine[j * 512 - (int)g.sub];
+              nb0.um[j] = mine[j * BLK - (int)g.sub];
+          }
+          if constexpr (TILE)
+          {
+            if (lds_bm && has_bm)
+              bm = mine[(R - 1) * BLK - (int)(t1 * g.sub)];
+            if (lds_bp && has_bp)
+              bp = mine[(int)(t1 * g.sub)];
           }
         }
         else
         {
           if (lds_m && has_bm)
-            bm = mine[(R - 1) * 512 - (int)g.sub];
+            bm = mine[(R - 1) * BLK - (int)g.sub];
           if (lds_p && has_bp)
             bp = mine[(int)g.sub];
         }
@@ -293,7 +411,7 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
         if (LDS && g.xl)
         {
           // exact rows cross wave boundaries: the x neighbours come from the rows just handed to LDS
-          const float4 *mine = hand + (size_t)(y & 1) * R * 512 + tid + j * 512;
+          const float4 *mine = hand + (size_t)(y & 1) * R * BLK + tid + j * BLK;
           lft = (first || !slot) ? 0.0f : mine[-1].w;
           rgt = (rightmost || !slot) ? 0.0f : mine[1].x;
         }
@@ -410,7 +528,12 @@ __global__ void __launch_bounds__(512, (MODE == MODE_A && D == 4 && STREAM && LD
         rv[j] = rn[j];
         qv[j] = qn[j];
       }
-      if constexpr (SHALLOW)
+      if constexpr (TILE)
+      {
+        t0 = t1r;
+        t1r = t2r;
+      }
+      else if constexpr (SHALLOW)
         nb0 = nb2;
       else
       {

@@ -158,6 +158,8 @@ struct RowsGeom
   int stream;            // k_cols: single-use traffic carries the streaming hint
   int xl;                // k_cols: a row takes exactly n0/4 lanes (x neighbours through LDS too)
   int lds_a, lds_b;      // k_cols, kernels A (and the plain stencil) / B: axis-1 neighbours inside a workgroup travel through LDS
+  unsigned xcd;          // k_cols, tiled slots: patches per XCD along axis 1 (0: patches are dealt to the XCDs in turn)
+  unsigned t2;           // k_cols in 4-D through LDS: slots of a workgroup along the blocks of axis d-2 (1: a strip along axis 1)
 };
 
 struct ScalarGeom

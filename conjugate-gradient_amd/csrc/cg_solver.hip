@@ -285,7 +285,7 @@ static unsigned long long choose_segments(unsigned long long ncols, unsigned lon
 
 // columns x segments decomposition of the rows engine (see cg_device.hpp)
 static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, RowsGeom &g, int &block, int &grid,
-                           unsigned s0 = 0, int per_cu = 0)
+                           unsigned s0 = 0, int per_cu = 0, bool for_kernel_a = false)
 {
   memset(&g, 0, sizeof(g));
   g.d = d;
@@ -369,7 +369,7 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
         g.sb = g.sk[d - 3];
         g.ncols = (unsigned)(nc / R);
         nc = g.ncols;
-        block = std::min(block, 512); // k_cols is bounded to 512 lanes
+        block = std::min(block, 512); // k_cols is bounded to 512 lanes (tiled slots: see below)
         g.cpg = (unsigned)block / sub;
         g.stream = env_int("CG_COLS_STREAM", big ? 1 : 0);
         // neighbours along axis 1 through LDS (see k_cols): kernel B always, kernel A where it measured faster
@@ -387,6 +387,42 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
         }
       }
       ncols = (nc + g.cpg - 1) / g.cpg; // column groups
+      // 4-D with the neighbours through LDS: the slots of a workgroup form a patch of axis 1 x blocks of axis 2
+      // (t1 x t2) instead of a strip along axis 1, so that half (t2 = 2) of the block-edge neighbours along
+      // axis 2 are rows of the same workgroup too.  For kernel A of large grids, which fetches every neighbour
+      // from two arrays (128^4: 662 -> 614 us); kernel B, whose neighbour loads mostly hit L2 anyway, loses
+      // (797 -> 847 us) and keeps the strip.
+      g.t2 = 1;
+      const bool wide = for_kernel_a && g.R == 2 && d == 4 && g.lds_a && g.lds_b && env_int("CG_COLS_BLOCK_A", 512) >= 1024;
+      if (wide)
+      {
+        block = 1024; // the tiled kernel has a 1024-lane variant
+        g.cpg = (unsigned)block / g.sub;
+        ncols = (nc + g.cpg - 1) / g.cpg;
+      }
+      if (g.R == 2 && d == 4 && g.lds_a && g.lds_b)
+      {
+        unsigned t2 = (unsigned)std::max(1, for_kernel_a ? env_int("CG_COLS_T2", big ? 2 : 1) : env_int("CG_COLS_T2_B", 1));
+        // exact rows leave an odd number of slots in a workgroup now and then: give one up (96^4: 21 -> 20)
+        if (t2 == 2 && g.cpg % 2 != 0 && g.cpg >= 5)
+        {
+          g.cpg -= 1;
+          ncols = (nc + g.cpg - 1) / g.cpg;
+        }
+        while (t2 > 1 && (g.cpg % t2 != 0 || g.cpg / t2 < 2))
+          t2--;
+        if (t2 == 1 && wide)
+          t2 = 2; // the strip kernel is bounded to 512 lanes
+        if (t2 > 1)
+        {
+          g.t2 = t2;
+          const unsigned long long t1 = g.cpg / t2, nblk = g.nb / (unsigned)g.R;
+          ncols = ((n[1] + t1 - 1) / t1) * ((nblk + t2 - 1) / t2);
+          const unsigned long long nt1 = (n[1] + t1 - 1) / t1;
+          // patches of one XCD side by side along axis 1 (128^4, kernel A: 598 -> 587 us, 2.79 -> 2.54 GB fetched)
+          g.xcd = (nt1 % 8 == 0 && env_int("CG_COLS_XCD", 1)) ? (unsigned)(nt1 / 8) : 0u;
+        }
+      }
     }
   }
   // scale the resident-workgroup target by the workgroup size (it is counted in 256-thread units)
@@ -399,6 +435,8 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
   CG_REQUIRE(items < (1ull << 32), "too many work items for the rows engine");
   g.bpc = (unsigned)bpc;
   g.nitems = (unsigned)items;
+  if (bpc != 1)
+    g.xcd = 0; // the XCD of a work item is only known when items are whole columns
   g.has_lo = has_lo;
   g.has_hi = has_hi;
   grid = (int)std::min<unsigned long long>(items, std::min<unsigned long long>(target, (unsigned long long)max_blocks()));
@@ -764,11 +802,7 @@ void Solver::build_geometry()
     // (rows of at least 16384 points: 32768 x 4096 341 -> 320, 16384^2 653 -> 606; 8192 x 16384 loses, 365 -> 388)
     const bool beyond = d == 2 && N_ >= (1ull << 27) && n[0] >= 16384u;
     const int per_cu_a = env_int("CG_BLOCKS_PER_CU_A", beyond ? 2 : 0);
-    rgA_ = rg_;
-    blockA_ = block_;
-    gridA_ = gridB_;
-    if (per_cu_a > 0)
-      make_rows_geom(d, n, desc_.has_lo, desc_.has_hi, rgA_, blockA_, gridA_, s0_, per_cu_a);
+    make_rows_geom(d, n, desc_.has_lo, desc_.has_hi, rgA_, blockA_, gridA_, s0_, per_cu_a, true);
   }
   else if (engine_ == ENGINE_PLANES)
   {
@@ -870,6 +904,21 @@ static void launch_rows_pol(const RowsGeom &g, const VecArgs &a, int grid, int b
       CG_COLS_LAUNCH(3, 2);
     else if (g.d == 3)
       CG_COLS_LAUNCH(3, 1);
+    else if (g.d == 4 && g.R == 2 && g.t2 > 1)
+    {
+      // tiled slots (the geometry guarantees the LDS hand-off for every mode)
+      if (block > 512)
+      {
+        if (stream)
+          hipLaunchKernelGGL((k_cols<MODE, GHOST, 4, 2, true, true, 2>), dim3(grid), dim3(block), 0, s, g, a);
+        else
+          hipLaunchKernelGGL((k_cols<MODE, GHOST, 4, 2, false, true, 2>), dim3(grid), dim3(block), 0, s, g, a);
+      }
+      else if (stream)
+        hipLaunchKernelGGL((k_cols<MODE, GHOST, 4, 2, true, true, 1>), dim3(grid), dim3(block), 0, s, g, a);
+      else
+        hipLaunchKernelGGL((k_cols<MODE, GHOST, 4, 2, false, true, 1>), dim3(grid), dim3(block), 0, s, g, a);
+    }
     else if (g.d == 4 && g.R == 2)
       CG_COLS_LAUNCH(4, 2);
     else if (g.d == 4)

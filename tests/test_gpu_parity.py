@@ -605,6 +605,43 @@ def test_blocked_columns_match_the_scalar_engine(lib, monkeypatch, ext, R, strea
     assert rel_l2(out[1][1], out[2][1]) <= 1e-5
 
 
+@pytest.mark.parametrize("t2", ["2", "4", "8"])
+@pytest.mark.parametrize("exact", ["0", "1"])
+@pytest.mark.parametrize("ext", [[64, 6, 4, 5], [32, 3, 6, 7], [16, 5, 3, 4], [128, 9, 2, 3], [64, 40, 34, 9], [96, 10, 6, 5],
+                                 [20, 9, 8, 7], [100, 7, 6, 5], [32, 32, 32, 8], [64, 17, 13, 6], [128, 16, 2, 40]],
+                         ids=lambda e: "x".join(map(str, e)))
+def test_tiled_slots_of_blocked_columns_match_the_scalar_engine(lib, monkeypatch, ext, t2, exact):
+    """4-D: the column slots of a workgroup as a patch of axis 1 x blocks of axis 2 (CG_COLS_T2 slots along axis 2;
+    large grids take 2 by themselves), every block-edge neighbour inside the patch through LDS.  Same check as for
+    the strip: the one-point-per-lane engine's bits, patches that hang over the grid's faces included."""
+    monkeypatch.delenv("CG_ENGINE", raising=False)
+    monkeypatch.setenv("CG_COLS_R", "2")
+    monkeypatch.setenv("CG_COLS_LDS_A", "1")
+    monkeypatch.setenv("CG_COLS_T2", t2)
+    monkeypatch.setenv("CG_COLS_EXACT", exact)
+    N = int(np.prod(ext))
+    b = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(b.data_ptr(), N, 34)
+    out = {}
+    for engine in (2, 1):
+        s = lib.make_solver(ext, engine=engine)
+        if engine == 1:
+            assert s.kernel_name == "k_cols"
+        x = torch.zeros(N, dtype=torch.float32, device="cuda")
+        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.iterate(1, use_graph=False)
+        s.sync()
+        x1 = x.cpu().numpy().copy()
+        s.iterate(11, use_graph=True)
+        iters, res, hist = s.finish(hist_len=12)
+        assert iters == 12
+        out[engine] = (x1, x.cpu().numpy(), np.array(hist))
+        s.close()
+    assert np.allclose(out[1][0], out[2][0], rtol=3e-7, atol=0)
+    assert np.allclose(out[1][2], out[2][2], rtol=1e-5)
+    assert rel_l2(out[1][1], out[2][1]) <= 1e-5
+
+
 # ---- grids that fit one workgroup: whole iterations in a single launch -------------------------
 
 def _solve(lib, ext, b, plan, mode=0):
