@@ -7,7 +7,9 @@
 // sums.  The host reads one double per outer iteration (|r|, for the reference's stop test) and runs
 // the control flow exactly as the reference does.
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
@@ -54,7 +56,12 @@ __device__ __forceinline__ void block_partial_f64(double acc, double *__restrict
     sh[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0)
-    part[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+  {
+    double v = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    for (unsigned k = 4; k < (blockDim.x >> 6); k++) // workgroups of more than four waves
+      v += sh[k];
+    part[blockIdx.x] = v;
+  }
 }
 
 // kernel S: w = A u and the partial sums of u.w (Ap and p.Ap of conjugate-gradient_cpu.cu:363-365 in one pass)
@@ -69,6 +76,107 @@ __global__ void __launch_bounds__(256) k_stencil_dot_f64(double *__restrict__ w,
     const double lv = laplace_at_f64(u, i, d, L);
     w[i] = lv;
     acc = fma(u[i], lv, acc);
+  }
+  block_partial_f64(acc, part, sh);
+}
+
+// Kernel S for grids with an even number of points per axis and d >= 2, as a march: a lane owns two
+// consecutive points of axis 0 at fixed coordinates of axes 1 .. d-2 and walks along the LAST axis with the
+// points behind, at and ahead of it in registers, so the neighbours with the longest stride are never fetched
+// twice; the neighbours along the middle axes and the two x neighbours are direct loads of lines that the
+// lanes next door fetch in the same step (they hit the caches).  Every element then leaves HBM about once:
+// 16 B per point instead of the 32 B of the one-point-per-lane kernel above, whose neighbours along the last
+// axis are a whole plane away (512^3: 875 -> 501 us, 2.5 -> 4.3 TB/s).  Same order of the terms (axis 0 first).
+// columns = N / L / 2 lanes in all; `seg` cuts the march into segments when there are few columns.
+// tiled: a workgroup's waves hold 128 points of axis 0 in consecutive rows of axis 1 (instead of a run of
+// consecutive points), so that most neighbours along axis 1 are loaded by the same workgroup (needs L % 128 == 0
+// and as many rows as waves).
+__global__ void __launch_bounds__(1024) k_stencil_dot_f64_march(double *__restrict__ w, const double *__restrict__ u,
+                                                                int d, unsigned L, unsigned long long columns,
+                                                                unsigned nseg, int tiled, double *__restrict__ part)
+{
+  __shared__ double sh[16];
+  double acc = 0;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned half = L / 2;
+  unsigned long long slast = 1; // stride of the last axis
+  for (int k = 0; k + 1 < d; k++)
+    slast *= L;
+  for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < columns * nseg; t += step)
+  {
+    const unsigned seg = (unsigned)(t / columns);
+    unsigned long long c = t % columns;
+    if (tiled)
+    {
+      // the columns of this workgroup-sized run, re-dealt: lane -> point pair of a 128-point chunk, wave -> row
+      const unsigned nw = blockDim.x >> 6, chunks = half / 64u;
+      const unsigned long long g = c / blockDim.x;
+      const unsigned long long row = (g / chunks) * nw + (threadIdx.x >> 6);
+      c = row * half + (g % chunks) * 64u + (threadIdx.x & 63u);
+    }
+    const unsigned x0 = (unsigned)(c % half) * 2u;
+    c /= half;
+    unsigned long long base = x0, s = L;
+    unsigned okm = 0, okp = 0; // neighbours inside the grid, one bit per middle axis
+    for (int k = 1; k + 1 < d; k++)
+    {
+      const unsigned ck = (unsigned)(c % L);
+      c /= L;
+      base += ck * s;
+      if (ck > 0)
+        okm |= 1u << k;
+      if (ck + 1 < L)
+        okp |= 1u << k;
+      s *= L;
+    }
+    const unsigned z0 = (unsigned)((unsigned long long)seg * L / nseg), z1 = (unsigned)((unsigned long long)(seg + 1) * L / nseg);
+    const double2 zero = make_double2(0.0, 0.0);
+    auto ld2 = [&](unsigned long long i) { return *reinterpret_cast<const double2 *>(u + i); };
+    double2 vm = z0 > 0 ? ld2(base + (unsigned long long)(z0 - 1) * slast) : zero;
+    double2 vc = ld2(base + (unsigned long long)z0 * slast);
+    double2 vp = z0 + 1 < L ? ld2(base + (unsigned long long)(z0 + 1) * slast) : zero;
+    for (unsigned z = z0; z < z1; z++)
+    {
+      const unsigned long long i = base + (unsigned long long)z * slast;
+      // two rows ahead (the last one a segment needs is row z1)
+      const double2 vpp = (z + 2 < L && z + 2 <= z1) ? ld2(i + 2 * slast) : zero;
+      // x neighbours: the lanes next door hold them, except across a wave's ends (and where a wave's lanes are
+      // not consecutive point pairs of one row: the plain dealing of lanes when a row is not a multiple of 128)
+      double lft = __shfl_up(vc.y, 1), rgt = __shfl_down(vc.x, 1);
+      const unsigned ln = threadIdx.x & 63u;
+      if (ln == 0 || !tiled)
+        lft = x0 > 0 ? u[i - 1] : 0.0;
+      if (ln == 63 || !tiled)
+        rgt = x0 + 2 < L ? u[i + 2] : 0.0;
+      if (x0 == 0)
+        lft = 0.0;
+      if (x0 + 2 >= L)
+        rgt = 0.0;
+      double l0 = 0, l1 = 0;
+      l0 = l0 + ((-vc.y + 2 * vc.x) - lft);
+      l1 = l1 + ((-rgt + 2 * vc.y) - vc.x);
+      unsigned long long sk = L;
+      for (int k = 1; k + 1 < d; k++)
+      {
+        const double2 up = (okp >> k) & 1u ? ld2(i + sk) : zero;
+        const double2 um = (okm >> k) & 1u ? ld2(i - sk) : zero;
+        l0 = l0 + ((-up.x + 2 * vc.x) - um.x);
+        l1 = l1 + ((-up.y + 2 * vc.y) - um.y);
+        sk *= L;
+      }
+      l0 = l0 + ((-vp.x + 2 * vc.x) - vm.x);
+      l1 = l1 + ((-vp.y + 2 * vc.y) - vm.y);
+      {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d out = {l0, l1};
+        __builtin_nontemporal_store(out, reinterpret_cast<v2d *>(w + i)); // w is read once, by the next kernel
+      }
+      acc = fma(vc.x, l0, acc);
+      acc = fma(vc.y, l1, acc);
+      vm = vc;
+      vc = vp;
+      vp = vpp;
+    }
   }
   block_partial_f64(acc, part, sh);
 }
@@ -233,6 +341,40 @@ extern "C" int preconditioned_cg_gpu(const double *b, double *x, int L, int d, i
   CHECK(hipMalloc((void **)&zf, N * sizeof(float)));
   const dim3 G(grid), B(256);
 
+  // kernel S: the march where the grid allows it (even L, d >= 2, enough columns to fill the chip)
+  const unsigned long long columns = d >= 2 ? N / (unsigned)L / 2 : 0;
+  unsigned nseg = 1;
+  // a lane has little in flight (two rows ahead), so the chip is filled with lanes, two rounds of 2048 per CU
+  // where the grid allows it, by cutting the march into segments of at least 16 rows (512^3: 2 segments 646 us,
+  // 4: 514, 8: 501, 16: 504; CG_MIXED_NSEG overrides)
+  while (columns * nseg < (1ull << 20) && nseg * 32u <= (unsigned)L)
+    nseg *= 2;
+  if (const char *ns = getenv("CG_MIXED_NSEG"))
+    nseg = (unsigned)std::max(1, std::min(atoi(ns), L / 4 > 0 ? L / 4 : 1));
+  const char *mm = getenv("CG_MIXED_MARCH"); // 0: never, 2: wherever the grid allows it, else: where it fills the chip
+  const int want = (mm && *mm) ? atoi(mm) : 1;
+  const bool march = want != 0 && d >= 2 && L % 2 == 0 && (columns * nseg >= 16384ull || want == 2) &&
+                     (((uintptr_t)xd | (uintptr_t)w | (uintptr_t)p) % 16) == 0;
+  // tiled lanes: 128-point chunks of axis 0 in consecutive rows (CG_MIXED_BLOCK lanes per workgroup, 1024: 16 rows)
+  const char *mb = getenv("CG_MIXED_BLOCK");
+  const int blockS = std::max(256, std::min(1024, (mb && *mb) ? atoi(mb) / 64 * 64 : 1024));
+  const bool tiled = march && L % 128 == 0 && (columns / ((unsigned)L / 2)) % (unsigned)(blockS / 64) == 0 &&
+                     columns % (unsigned)blockS == 0;
+  const int blockM = tiled ? blockS : 256;
+  const int gridS = march ? (int)std::min<unsigned long long>((columns * nseg + blockM - 1) / blockM, (unsigned long long)grid) : grid;
+  auto stencil_dot = [&](double *out, const double *in) {
+    if (march)
+    {
+      // fewer workgroups than `grid` may write partials: the rest must read as zero
+      if (gridS < grid)
+        CHECK(hipMemsetAsync(partS, 0, (size_t)grid * sizeof(double), s));
+      hipLaunchKernelGGL(k_stencil_dot_f64_march, dim3(gridS), dim3(blockM), 0, s, out, in, d, (unsigned)L, columns, nseg,
+                         tiled ? 1 : 0, partS);
+    }
+    else
+      hipLaunchKernelGGL(k_stencil_dot_f64, G, B, 0, s, out, in, d, (unsigned)L, n32, partS);
+  };
+
   int ncalls = 0;
   // zf = M^-1 r: float CG from 0 on the float copy of r until |r_inner| <= 1e-3 |r| on the fresh residual, no
   // cap (conjugate-gradient_cpu.cu:274-324)
@@ -249,7 +391,7 @@ extern "C" int preconditioned_cg_gpu(const double *b, double *x, int L, int d, i
   };
 
   // r = b - A x (:340-344), tol = 1e-8 |b| (:345)
-  hipLaunchKernelGGL(k_stencil_dot_f64, G, B, 0, s, w, xd, d, (unsigned)L, n32, partS);
+  stencil_dot(w, xd);
   hipLaunchKernelGGL(k_residual_f64, G, B, 0, s, r, rf, bd, w, n32);
   hipLaunchKernelGGL(k_dot_f64, G, B, 0, s, bd, bd, n32, partD);
   const double tol = 1e-8 * sqrt(read_sum(partD));
@@ -263,7 +405,7 @@ extern "C" int preconditioned_cg_gpu(const double *b, double *x, int L, int d, i
   {
     const int parity = it & 1;
     it++;
-    hipLaunchKernelGGL(k_stencil_dot_f64, G, B, 0, s, w, p, d, (unsigned)L, n32, partS);
+    stencil_dot(w, p);
     hipLaunchKernelGGL(k_update_dot_f64, G, B, 0, s, xd, r, rf, p, w, n32, st, parity, partS, grid, partU);
     if (sqrt(read_sum(partU)) < tol)
       break;

@@ -322,6 +322,26 @@ def test_mixed_precision_matches_fp64_reference(lib, oracle):
     assert rel_l2(xf.cpu().numpy(), g["x_pcg"]) > rel_l2(x, g["x_pcg"])
 
 
+@pytest.mark.parametrize("L,d", [(50, 2), (64, 3), (32, 3), (16, 4), (12, 5), (256, 2)])
+def test_outer_loop_stencil_as_a_march_gives_the_same_solve(lib, monkeypatch, L, d):
+    """The fp64 stencil + dot of the outer loop (conjugate-gradient_cpu.cu:363-365) has two kernels: one point
+    per lane, and a march along the last axis (two points of axis 0 per lane, grids with an even L).  Both add
+    the stencil's terms in the reference's order, so forcing either one changes only the order in which the
+    partial sums of p.Ap are added: same outer and inner iteration counts, solutions equal to 1e-12."""
+    N = L ** d
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    b = torch.rand(N, dtype=torch.float64, device="cuda", generator=gen)
+    out = {}
+    for want in ("0", "2"):
+        monkeypatch.setenv("CG_MIXED_MARCH", want)
+        x = torch.zeros(N, dtype=torch.float64, device="cuda")
+        out[want] = (lib.preconditioned_cg_gpu(b.data_ptr(), x.data_ptr(), L, d), x)
+    assert out["0"][0] == out["2"][0]
+    assert out["0"][0][0] >= 1
+    err = (out["0"][1] - out["2"][1]).abs().max().item() / out["0"][1].abs().max().item()
+    assert err <= 1e-12, err
+
+
 # ---- size-independent properties at larger sizes ---------------------------------------
 
 @pytest.mark.parametrize("L,d", [(2048, 2), (128, 3), (32, 4)])
