@@ -164,9 +164,33 @@ static void test_neighbour_index_device(unsigned int L, unsigned int d, int inde
   OK(hipFree(out));
 }
 
+// the reference's unused device helpers (conjugate-gradient_gpu.cuh:12-14) keep their meaning
+__global__ void cords_on_device(int *out)
+{
+  int c[3];
+  index_to_cords_cu(c, 4 + 5 * (2 + 5 * 3), 5, 3); // coordinates (4, 2, 3), axis 0 fastest
+  out[0] = c[0];
+  out[1] = c[1];
+  out[2] = c[2];
+  int rev[3] = {3, 2, 4};
+  out[3] = get_index_gpu(rev, 5, 3, 125); // cords[0] is the most significant digit there
+}
+
+static void test_dead_device_helpers()
+{
+  int *out;
+  OK(hipMallocManaged((void **)&out, 4 * sizeof(int)));
+  cords_on_device<<<1, 1>>>(out);
+  OK(hipDeviceSynchronize());
+  assert(out[0] == 4 && out[1] == 2 && out[2] == 3);
+  assert(out[3] == 4 + 5 * (2 + 5 * 3));
+  OK(hipFree(out));
+}
+
 int main()
 {
   test_cpu_side();
+  test_dead_device_helpers();
   test_neighbour_index_device(5, 3, 0);
   test_neighbour_index_device(10, 2, 1);
   test_neighbour_index_device(8, 3, 2);

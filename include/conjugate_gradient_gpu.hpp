@@ -65,3 +65,32 @@ extern "C" __device__ inline unsigned int neighbour_index_gpu(unsigned int ind, 
     return N;
   return ind + (unsigned int)(amount * n);
 }
+
+// conjugate-gradient_gpu.cuh:12-14 declare two more __device__ helpers that nothing in the reference calls
+// (conjugate-gradient_gpu.cu:57-93); they are kept so that a caller's kernel written against that header
+// still compiles.  index_to_cords_cu: cords[i] = coordinate of `index` along axis i, axis 0 fastest (the layout
+// of every vector here).  get_index_gpu: Horner's rule over cords[0], cords[1], ... -- cords[0] ends up as the
+// MOST significant digit, the opposite of index_to_cords_cu (the reference's own inconsistency; the two are
+// inverses of each other only for palindromic coordinates).  N is unused, as in the reference.
+__device__ inline int *index_to_cords_cu(int *cords, int index, int L, int d)
+{
+  for (int i = 0; i < d; i++)
+  {
+    cords[i] = index % L;
+    index /= L;
+  }
+  return cords;
+}
+
+__device__ inline int get_index_gpu(int *cords, int L, int d, int N)
+{
+  (void)N;
+  int index = 0;
+  for (int i = 0; i < d; i++)
+  {
+    index += cords[i];
+    if (i < d - 1)
+      index *= L;
+  }
+  return index;
+}
