@@ -139,6 +139,12 @@ int Solver::bind_rccl(void *comm, int rank, int world, int lo_rank, int hi_rank)
   comm_world_ = world;
   lo_rank_ = lo_rank;
   hi_rank_ = hi_rank;
+  {
+    // planes of at least CG_RCCL_OVERLAP_BYTES (default 256 KiB) travel beside kernel B, smaller ones after it
+    const char *e = getenv("CG_RCCL_OVERLAP_BYTES");
+    const long long least = (e && *e) ? atoll(e) : (256ll << 10);
+    halo_overlap_ = (long long)(plane_ * sizeof(float)) >= least;
+  }
   rccl_ = true;
   bind_sums(gathered(0), world, gathered(1), world);
   // set every connection up outside any stream capture: one all-gather, one plane exchange (r's ghost
@@ -181,6 +187,11 @@ void Solver::rccl_exchange_from_r()
 {
   if (lo_rank_ < 0 && hi_rank_ < 0)
     return;
+  if (!halo_overlap_)
+  {
+    rccl_send_recv(r_, r_ + N_ - plane_, stream_);
+    return;
+  }
   CHECK(hipEventRecord(ev_fork_, stream_));
   CHECK(hipStreamWaitEvent(side_, ev_fork_, 0));
   rccl_send_recv(r_, r_ + N_ - plane_, side_);

@@ -1415,7 +1415,9 @@ void Solver::edge_update(hipStream_t s)
   e.edge = edge_;
   e.plane = plane_;
   e.pad = edge_pad_;
-  const int blocks = (int)std::max<size_t>(1, std::min<size_t>((plane_ + 255) / 256, 256));
+  // one point per lane and side where the plane allows it: every point costs a chain of dependent neighbour
+  // loads, so few lanes with many points each would be bound by latency (a 1024 x 1024 plane on 256 workgroups: 90 us)
+  const int blocks = (int)std::max<size_t>(1, std::min<size_t>((plane_ + 255) / 256, 8192));
   hipLaunchKernelGGL(k_edge_r, dim3(blocks), dim3(256), 0, s, sg_, e);
   CHECK(hipGetLastError());
 }
@@ -1518,7 +1520,13 @@ void Solver::launch_iteration(bool may_defer, hipEvent_t *ev)
   // with a communicator bound and slab neighbours, r's boundary planes travel on the side stream while kernel
   // B runs: [side] copy of the planes (beside kernel A) -> [after the p.Ap exchange] edge_update -> send / recv
   // into the neighbours' ghost planes of r, which nothing reads before the next kernel A
-  const bool halo = rccl_ && (desc_.has_lo || desc_.has_hi);
+  // Small planes (2-D slabs: one row) are latency, not bytes: they go after kernel B on the same stream, and
+  // the iteration stays a chain of nodes.  (Every dependency between the two streams costs the graph about
+  // 13 us even when it is long satisfied, measured with one rank as its own neighbour: the overlapped form is
+  // 27 us per iteration at 8192^2 and 39 us on a 1024 x 1024 x 128 slab above the plain solver, two 4.5-us
+  // all-gathers included.  That pays where a plane takes longer than that to cross a link.)
+  const bool halo = rccl_ && halo_overlap_ && (desc_.has_lo || desc_.has_hi);
+  const bool halo_serial = rccl_ && !halo_overlap_ && (desc_.has_lo || desc_.has_hi);
   if (ev)
     CHECK(hipEventRecord(ev[0], stream_));
   if (halo)
@@ -1553,6 +1561,8 @@ void Solver::launch_iteration(bool may_defer, hipEvent_t *ev)
     launch_exchange(1, false);
   else if (rccl_)
     rccl_allgather(1);
+  if (halo_serial)
+    rccl_send_recv(r_, r_ + N_ - plane_, stream_);
   if (halo)
     CHECK(hipStreamWaitEvent(stream_, ev_join_, 0)); // the next kernel A reads r's ghost planes
   if (ev)
@@ -1617,7 +1627,7 @@ void Solver::iterate(int n, bool use_graph)
     // when the graph is built -- RCCL 2.26 / ROCm 7.0 -- while on the capture's own stream it is fine, and so
     // are collectives on a forked stream.)  A graph is a DAG either way: replay does not care which stream a
     // node was recorded on.
-    const bool halo = rccl_ && (desc_.has_lo || desc_.has_hi);
+    const bool halo = rccl_ && halo_overlap_ && (desc_.has_lo || desc_.has_hi);
     if (halo)
     {
       CHECK(hipEventRecord(ev_cap_begin_, stream_));

@@ -181,6 +181,7 @@ private:
   void *comm_ = nullptr;     // ncclComm_t
   int comm_rank_ = 0, comm_world_ = 1;
   int lo_rank_ = -1, hi_rank_ = -1;
+  bool halo_overlap_ = true; // the planes travel beside kernel B (large planes) or after it on stream_ (small ones)
   void *comm_halo_ = nullptr; // ncclComm_t for the plane exchange (split off comm_; comm_ itself if that failed)
   bool own_halo_comm_ = false;
   // rank_sums_[0..1]: this rank's p.Ap / r.r; then [2][CG_RCCL_MAX_RANKS] every rank's, gathered; then two tickets

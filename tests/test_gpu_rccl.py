@@ -87,13 +87,16 @@ def mirror_reference(lib, ext, b, plan):
     return x, out
 
 
+@pytest.mark.parametrize("overlap_bytes", ["0", "1000000000"], ids=["beside_kernel_B", "after_kernel_B"])
 @pytest.mark.parametrize("ext", [[256, 256], [1024, 512], [64, 64, 16], [256, 64, 32], [1024, 256, 16], [32, 32, 32, 32], [16, 16, 16, 8, 8]])
-def test_ring_of_one_rank_runs_the_whole_multi_rank_machinery(lib, ext):
+def test_ring_of_one_rank_runs_the_whole_multi_rank_machinery(lib, monkeypatch, ext, overlap_bytes):
     """One RCCL rank that is its own lower and upper neighbour (cg_solver_bind_rccl_peers with lo = hi = 0): the
     all-gathers of the per-rank sums, the side stream, the boundary planes computed ahead of kernel B and the
     grouped ncclSend / ncclRecv into the ghost planes all run as they do between GPUs -- from plain launches
     and replayed from the captured graph -- and must reproduce the step interface with hand-copied planes bit
-    for bit."""
+    for bit.  Both forms of the plane exchange: beside kernel B on the second stream (what planes of at least
+    CG_RCCL_OVERLAP_BYTES take, 256 KiB by default) and after kernel B on the solver's stream."""
+    monkeypatch.setenv("CG_RCCL_OVERLAP_BYTES", overlap_bytes)
     N = int(np.prod(ext))
     b = torch.empty(N, dtype=torch.float32, device="cuda")
     lib.c.cg_fill_uniform(b.data_ptr(), N, 13)
