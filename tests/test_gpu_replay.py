@@ -7,6 +7,7 @@ reduction does).  Tolerances: every entry of the r.r history within 1e-4 relativ
 1e-4 relative L2.  The Morton run gets the same vector permuted into Z-order and must reproduce
 the lexicographic replay after permuting x back."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -135,3 +136,22 @@ def test_replay_morton_128_4(lib, monkeypatch, relayout):
     x = torch.empty_like(xm)
     x[perm] = xm
     check(x, hist, x_ref, hist_ref)
+
+
+def test_benchmark_of_a_morton_ordered_grid_reports_both_paths(tmp_path):
+    """bench.py on vectors in Morton order: `value` is a whole 200-iteration solve with the permutation passes of
+    the lexicographic-inside path, and the Z-curve kernels are timed beside it with their own roofline object."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "128x128x128:2", "--steps", "10",
+                        "--warmup", "2", "--repeats", "3", "--no-cpu-baseline", "--no-traffic"],
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    m = out["morton"]
+    assert out["config"]["index_mode"] == 2 and "lexicographic" in out["config"]["ran"]
+    assert out["value"] == m["iterations_per_sec_of_a_200_iteration_solve"] < m["hot_loop_iterations_per_sec"]
+    assert m["begin_finish_ms"] > 0 and m["native"]["roofline"]["kernel"].startswith("k_morton")
+    assert 0 < m["native"]["hbm_frac_moved"] <= 1 and 0 < out["roofline"]["frac"] <= 1
