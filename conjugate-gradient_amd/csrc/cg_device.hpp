@@ -404,7 +404,10 @@ enum
   // halo rows and planes of p that neighbouring tiles re-read, and part of what kernel B read last
   // and kernel A reads first, are then served on-die.  The planes engine's default (3-D,
   // 1024 x 1024 x 128: kernel A 342 -> 316 us, kernel B 447 -> 456 us).
-  POL_KEEP_RP = 2
+  POL_KEEP_RP = 2,
+  // everything streams, r included: for grids whose vectors exceed the cache several times over, where keeping
+  // r resident buys nothing (rows engine only)
+  POL_STREAM = 3
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -449,7 +452,8 @@ struct Src
 {
   // p streams past the cache under POL_KEEP_R (in every mode but the plain stencil, whose
   // input is re-read by neighbouring rows of other workgroups); r is what the cache keeps
-  static constexpr bool NT_P = (POL == POL_KEEP_R) && (MODE != MODE_STENCIL);
+  static constexpr bool NT_P = (POL == POL_KEEP_R || POL == POL_STREAM) && (MODE != MODE_STENCIL);
+  static constexpr bool NT_R = POL == POL_STREAM;
   const float *__restrict__ p;
   const float *__restrict__ r;
   float beta;
@@ -457,7 +461,7 @@ struct Src
   {
     float v = load1<NT_P>(p + i);
     if constexpr (MODE == MODE_A)
-      v = fmaf(beta, v, load1<false>(r + i));
+      v = fmaf(beta, v, load1<NT_R>(r + i));
     return v;
   }
   __device__ __forceinline__ float4 ld4(long long i) const
@@ -465,7 +469,7 @@ struct Src
     float4 v = load4<NT_P>(p + i);
     if constexpr (MODE == MODE_A)
     {
-      const float4 q = load4<false>(r + i);
+      const float4 q = load4<NT_R>(r + i);
       v.x = fmaf(beta, v.x, q.x);
       v.y = fmaf(beta, v.y, q.y);
       v.z = fmaf(beta, v.z, q.z);
@@ -514,7 +518,8 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
   static_assert(!PACK || D == 0 || D == 3, "packed rows exist for d >= 3 only");
   __shared__ double sh[16];
   const int tid = threadIdx.x, lane = tid & 63;
-  constexpr bool NT = POL == POL_KEEP_R; // x, the stores of r and of p_new
+  constexpr bool NT = POL == POL_KEEP_R || POL == POL_STREAM; // x, the stores of r and of p_new
+  constexpr bool NT_R = POL == POL_STREAM;                     // kernel B's loads of r
   Src<MODE, POL> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
@@ -663,7 +668,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
         xv = load4<NT>(a.x + col0 + y0 * rs);
       if (xm == 2)
         qv = load4<Src<MODE, POL>::NT_P>(p_prev + col0 + y0 * rs);
-      rv = load4<false>(a.r + col0 + y0 * rs);
+      rv = load4<NT_R>(a.r + col0 + y0 * rs);
     }
     if constexpr (MODE == MODE_A)
     {
@@ -687,7 +692,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
             xn = load4<NT>(a.x + col0 + (y + 1) * rs);
           if (xm == 2)
             qn = load4<Src<MODE, POL>::NT_P>(p_prev + col0 + (y + 1) * rs);
-          rn = load4<false>(a.r + col0 + (y + 1) * rs);
+          rn = load4<NT_R>(a.r + col0 + (y + 1) * rs);
         }
       }
 

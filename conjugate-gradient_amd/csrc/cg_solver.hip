@@ -658,6 +658,20 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   policy_ = env_int("CG_CACHE_POLICY", engine_ == ENGINE_PLANES ? POL_KEEP_RP : (keep_r ? POL_KEEP_R : POL_PLAIN));
   if (policy_ == POL_KEEP_RP && engine_ != ENGINE_PLANES)
     policy_ = POL_KEEP_R; // the third policy exists for the planes engine only
+  if (policy_ == POL_STREAM && engine_ != ENGINE_ROWS)
+    policy_ = POL_KEEP_R; // ... and the fourth for the rows engine
+  // Kernel A of the rows engine in 1-D and 2-D on grids whose vectors no longer fit the Infinity Cache (from
+  // 9/8 of its 256 MiB on) streams r as well: little of it survives until kernel B anyway, and the cache then
+  // serves kernel A's own stream better (kernel A: 9216 x 8192 195 -> 178 us, 10240 x 8192 234 -> 200, 16384 x
+  // 8192 316 -> 302, 16384^2 596 -> 573, 1-D 2^27 364 -> 328; 8192^2, which fits, loses: 130 -> 145; kernel B
+  // with the same policy loses 5 %, so it keeps r cached).  CG_CACHE_POLICY_A overrides.
+  policy_a_ = policy_;
+  if (engine_ == ENGINE_ROWS && desc_.d <= 2 && policy_ == POL_KEEP_R && N_ >= (1ull << 26) + (1ull << 23))
+    policy_a_ = POL_STREAM;
+  policy_a_ = env_int("CG_CACHE_POLICY_A", policy_a_);
+  if ((policy_a_ == POL_STREAM && engine_ != ENGINE_ROWS) || (policy_a_ == POL_KEEP_RP && engine_ != ENGINE_PLANES) ||
+      policy_a_ < POL_PLAIN || policy_a_ > POL_STREAM)
+    policy_a_ = policy_;
   sumA_ = partA_;
   sumB_ = partB_;
   nA_ = nB_ = grid_;
@@ -883,7 +897,7 @@ static void launch_rows_pol(const RowsGeom &g, const VecArgs &a, int grid, int b
   if (g.sub && g.R)
   {
     // blocked columns: the streaming hint is the geometry's choice (grid size) or a forced cache policy
-    const bool stream = g.stream || POL == POL_KEEP_R;
+    const bool stream = g.stream || POL == POL_KEEP_R || POL == POL_STREAM;
 #define CG_COLS_LAUNCH_L(DD, RR, LL)                                                                        \
   do                                                                                                        \
   {                                                                                                         \
@@ -952,6 +966,10 @@ template <int MODE, bool GHOST>
 static void launch_rows(const RowsGeom &g, const VecArgs &a, int grid, int block, hipStream_t s, int pol = POL_PLAIN)
 {
   if (pol == POL_KEEP_R && MODE != MODE_STENCIL)
+    launch_rows_pol<MODE, GHOST, POL_KEEP_R>(g, a, grid, block, s);
+  else if (pol == POL_STREAM && MODE != MODE_STENCIL && !g.sub && g.d <= 2)
+    launch_rows_pol<MODE, GHOST, POL_STREAM>(g, a, grid, block, s);
+  else if (pol == POL_STREAM && MODE != MODE_STENCIL)
     launch_rows_pol<MODE, GHOST, POL_KEEP_R>(g, a, grid, block, s);
   else
     launch_rows_pol<MODE, GHOST, POL_PLAIN>(g, a, grid, block, s);
@@ -1024,7 +1042,7 @@ void Solver::launch_mode(int mode, bool ghost, const VecArgs &a)
   {
     switch (mode)
     {
-    case MODE_A: launch_morton4<MODE_A>(mg_, a, gridA_, blockA_, stream_, policy_); break;
+    case MODE_A: launch_morton4<MODE_A>(mg_, a, gridA_, blockA_, stream_, policy_a_); break;
     case MODE_B: launch_morton4<MODE_B>(mg_, a, gridB_, block_, stream_, policy_); break;
     default: launch_morton4<MODE_STENCIL>(mg_, a, gridB_, block_, stream_);
     }
@@ -1033,7 +1051,7 @@ void Solver::launch_mode(int mode, bool ghost, const VecArgs &a)
   {
     switch (mode)
     {
-    case MODE_A: launch_planes<MODE_A, true>(pgA_, a, gridA_, blockA_, planes_r_, stream_, policy_); break;
+    case MODE_A: launch_planes<MODE_A, true>(pgA_, a, gridA_, blockA_, planes_r_, stream_, policy_a_); break;
     case MODE_B: launch_planes<MODE_B, true>(pg_, a, gridB_, block_, planes_r_, stream_, policy_); break;
     default:
       if (ghost)
@@ -1046,7 +1064,7 @@ void Solver::launch_mode(int mode, bool ghost, const VecArgs &a)
   {
     switch (mode)
     {
-    case MODE_A: launch_rows<MODE_A, true>(rgA_, a, gridA_, blockA_, stream_, policy_); break;
+    case MODE_A: launch_rows<MODE_A, true>(rgA_, a, gridA_, blockA_, stream_, policy_a_); break;
     case MODE_B: launch_rows<MODE_B, true>(rg_, a, gridB_, block_, stream_, policy_); break;
     default:
       if (ghost)

@@ -148,7 +148,8 @@ private:
   CgState *st_ = nullptr;
   CgState *st_host_ = nullptr;
   int engine_ = ENGINE_SCALAR;
-  int policy_ = POL_KEEP_R;
+  int policy_ = POL_KEEP_R;   // kernel B (and what both kernels share)
+  int policy_a_ = POL_KEEP_R; // kernel A
   bool xdefer_ = false; // kernel B of this solver's engine implements the paired x update
   bool last_deferred_ = false;  // the last kernel B enqueued left x alone: the next one must not
   bool may_be_pending_ = false; // a kernel B that may have left x alone was enqueued since the last flush_x()

@@ -662,6 +662,33 @@ def test_tiled_slots_of_blocked_columns_match_the_scalar_engine(lib, monkeypatch
     assert rel_l2(out[1][1], out[2][1]) <= 1e-5
 
 
+@pytest.mark.parametrize("ext", [[2048, 1024], [1 << 21], [1000, 700], [512, 64, 32], [64, 64, 64, 8]], ids=lambda e: "x".join(map(str, e)))
+@pytest.mark.parametrize("env", [{"CG_CACHE_POLICY": "0"}, {"CG_CACHE_POLICY": "1"}, {"CG_CACHE_POLICY": "3"},
+                                 {"CG_CACHE_POLICY_A": "3"}, {"CG_CACHE_POLICY": "2", "CG_CACHE_POLICY_A": "1"}],
+                         ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()))
+def test_cache_policies_change_no_bit(lib, monkeypatch, ext, env):
+    """The cache policies (plain accesses, r kept in the Infinity Cache, r and p kept, everything streaming; one for
+    kernel A and one for kernel B) only choose between temporal and non-temporal loads and stores: a solve under
+    any of them has the automatic choice's bits, whichever engine the grid takes (a policy that does not exist
+    for that engine falls back)."""
+    N = int(np.prod(ext))
+    b = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(b.data_ptr(), N, 35)
+    out = []
+    for use_env in (False, True):
+        for k, v in env.items():
+            if use_env:
+                monkeypatch.setenv(k, v)
+        s = lib.make_solver(ext)
+        x = torch.zeros(N, dtype=torch.float32, device="cuda")
+        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.iterate(13)
+        out.append((s.finish(hist_len=13), x))
+        s.close()
+    assert out[0][0] == out[1][0] and out[0][0][0] == 13
+    assert torch.equal(out[0][1], out[1][1])
+
+
 # ---- grids that fit one workgroup: whole iterations in a single launch -------------------------
 
 def _solve(lib, ext, b, plan, mode=0):
