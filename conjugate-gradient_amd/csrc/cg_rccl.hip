@@ -123,15 +123,26 @@ int Solver::bind_rccl(void *comm, int rank, int world, int lo_rank, int hi_rank)
   ncclComm_t halo = nullptr;
   const char *shared = getenv("CG_RCCL_SHARED_COMM"); // 1: no second communicator (every rank alike)
   const ncclResult_t sp = (shared && *shared == '1') ? ncclInvalidUsage : ncclCommSplit(c, 0, rank, &halo, nullptr);
-  if (sp == ncclSuccess && halo)
+  // every rank must end up with the same choice: agree on it (minimum over the ranks of "my split worked")
+  int *flag = reinterpret_cast<int *>(rank_sums_);
+  int mine = (sp == ncclSuccess && halo) ? 1 : 0, all = 0;
+  CHECK(hipMemcpy(flag, &mine, sizeof(int), hipMemcpyHostToDevice));
+  RCCL_TRY(ncclAllReduce(flag, flag + 1, 1, ncclInt, ncclMin, c, stream_));
+  CHECK(hipStreamSynchronize(stream_));
+  CHECK(hipMemcpy(&all, flag + 1, sizeof(int), hipMemcpyDeviceToHost));
+  CHECK(hipMemset(rank_sums_, 0, bytes));
+  if (all)
   {
     comm_halo_ = halo;
     own_halo_comm_ = true;
   }
   else
   {
+    if (mine)
+      (void)ncclCommDestroy(halo);
     if (!(shared && *shared == '1'))
-      fprintf(stderr, "RCCL: ncclCommSplit failed (%s); boundary planes share the communicator\n", ncclGetErrorString(sp));
+      fprintf(stderr, "RCCL: ncclCommSplit failed on some rank (here: %s); boundary planes share the communicator\n",
+              ncclGetErrorString(sp));
     comm_halo_ = comm;
   }
   comm_ = comm;
