@@ -19,7 +19,7 @@
 namespace cgamd
 {
 
-constexpr int CG_SMALL_PPT = 8;                       // points per lane
+constexpr int CG_SMALL_PPT = 16;                      // points per lane, at most (8 for grids of up to 8192 points)
 constexpr int CG_SMALL_THREADS = 1024;
 constexpr int CG_SMALL_MAX = CG_SMALL_PPT * CG_SMALL_THREADS;
 constexpr int CG_SMALL_MAXD = 8;                      // 2 validity bits per axis in a 16-bit mask
@@ -50,10 +50,13 @@ __device__ __forceinline__ double small_block_sum(float acc, double *sh)
 }
 
 // D: compile-time dimension (1..4) so that the axis loops unroll; 0 = run-time g.d
-template <int LAYOUT, int D>
+// PPT: points per lane (8: up to 8192 points, 2.75 us per iteration; 16: up to 16384, about twice that, still
+// below the two launches of the two-kernel iteration)
+template <int LAYOUT, int D, int PPT>
 __global__ void __launch_bounds__(CG_SMALL_THREADS) k_small(const SmallGeom g, const VecArgs a, double *partB, int nB)
 {
-  __shared__ float pl[CG_SMALL_MAX];
+  static_assert(PPT <= CG_SMALL_PPT, "more points per lane than the geometry allows");
+  __shared__ float pl[PPT * CG_SMALL_THREADS];
   __shared__ double sh[CG_SMALL_THREADS / 64];
   __shared__ double shb[8];
   CgState *st = a.st;
@@ -70,11 +73,11 @@ __global__ void __launch_bounds__(CG_SMALL_THREADS) k_small(const SmallGeom g, c
   const int k_in = k;
 
   // ---- load this lane's points; neighbour validity is computed once ------------------------
-  float x[CG_SMALL_PPT], r[CG_SMALL_PPT], p[CG_SMALL_PPT];
-  unsigned okbits[CG_SMALL_PPT];
+  float x[PPT], r[PPT], p[PPT];
+  unsigned okbits[PPT];
   const float *p_in = (k & 1) ? a.p1 : a.p0;
 #pragma unroll
-  for (int j = 0; j < CG_SMALL_PPT; j++)
+  for (int j = 0; j < PPT; j++)
   {
     const unsigned i = (unsigned)tid + (unsigned)CG_SMALL_THREADS * j;
     const bool in = i < g.N;
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(CG_SMALL_THREADS) k_small(const SmallGeom g, c
 
     // ---- p = r + beta p, into LDS -------------------------------------------------------------
 #pragma unroll
-    for (int j = 0; j < CG_SMALL_PPT; j++)
+    for (int j = 0; j < PPT; j++)
     {
       p[j] = fmaf(beta, p[j], r[j]);
       pl[tid + CG_SMALL_THREADS * j] = p[j];
@@ -138,10 +141,10 @@ __global__ void __launch_bounds__(CG_SMALL_THREADS) k_small(const SmallGeom g, c
     __syncthreads();
 
     // ---- A p and p . A p ----------------------------------------------------------------------
-    float ap[CG_SMALL_PPT];
+    float ap[PPT];
     float acc = 0;
 #pragma unroll
-    for (int j = 0; j < CG_SMALL_PPT; j++)
+    for (int j = 0; j < PPT; j++)
     {
       ap[j] = 0.0f;
       if (j >= nj) // no lane has a point in this slot (uniform)
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(CG_SMALL_THREADS) k_small(const SmallGeom g, c
     // ---- x += alpha p ; r -= alpha A p ; r . r --------------------------------------------------
     acc = 0;
 #pragma unroll
-    for (int j = 0; j < CG_SMALL_PPT; j++)
+    for (int j = 0; j < PPT; j++)
     {
       x[j] = fmaf(alpha, p[j], x[j]);
       r[j] = fmaf(-alpha, ap[j], r[j]);
@@ -196,7 +199,7 @@ __global__ void __launch_bounds__(CG_SMALL_THREADS) k_small(const SmallGeom g, c
   // ---- leave everything as kernel B would have --------------------------------------------------
   float *p_out = (k & 1) ? a.p1 : a.p0;
 #pragma unroll
-  for (int j = 0; j < CG_SMALL_PPT; j++)
+  for (int j = 0; j < PPT; j++)
   {
     const unsigned i = (unsigned)tid + (unsigned)CG_SMALL_THREADS * j;
     if (i < g.N)

@@ -1587,18 +1587,27 @@ void Solver::launch_iteration(bool may_defer, hipEvent_t *ev)
     CHECK(hipEventRecord(ev[4], stream_));
 }
 
-template <int LAYOUT>
-static void launch_small_d(const SmallGeom &g, const VecArgs &a, double *partB, int nB, hipStream_t s)
+template <int LAYOUT, int PPT>
+static void launch_small_dp(const SmallGeom &g, const VecArgs &a, double *partB, int nB, hipStream_t s)
 {
   const dim3 G(1), B(CG_SMALL_THREADS);
   switch (g.d)
   {
-  case 1: hipLaunchKernelGGL((k_small<LAYOUT, 1>), G, B, 0, s, g, a, partB, nB); break;
-  case 2: hipLaunchKernelGGL((k_small<LAYOUT, 2>), G, B, 0, s, g, a, partB, nB); break;
-  case 3: hipLaunchKernelGGL((k_small<LAYOUT, 3>), G, B, 0, s, g, a, partB, nB); break;
-  case 4: hipLaunchKernelGGL((k_small<LAYOUT, 4>), G, B, 0, s, g, a, partB, nB); break;
-  default: hipLaunchKernelGGL((k_small<LAYOUT, 0>), G, B, 0, s, g, a, partB, nB);
+  case 1: hipLaunchKernelGGL((k_small<LAYOUT, 1, PPT>), G, B, 0, s, g, a, partB, nB); break;
+  case 2: hipLaunchKernelGGL((k_small<LAYOUT, 2, PPT>), G, B, 0, s, g, a, partB, nB); break;
+  case 3: hipLaunchKernelGGL((k_small<LAYOUT, 3, PPT>), G, B, 0, s, g, a, partB, nB); break;
+  case 4: hipLaunchKernelGGL((k_small<LAYOUT, 4, PPT>), G, B, 0, s, g, a, partB, nB); break;
+  default: hipLaunchKernelGGL((k_small<LAYOUT, 0, PPT>), G, B, 0, s, g, a, partB, nB);
   }
+}
+
+template <int LAYOUT>
+static void launch_small_d(const SmallGeom &g, const VecArgs &a, double *partB, int nB, hipStream_t s)
+{
+  if (g.N <= 8u * CG_SMALL_THREADS)
+    launch_small_dp<LAYOUT, 8>(g, a, partB, nB, s);
+  else
+    launch_small_dp<LAYOUT, 16>(g, a, partB, nB, s);
 }
 
 void Solver::launch_small()

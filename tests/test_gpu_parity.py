@@ -711,9 +711,13 @@ def _solve(lib, ext, b, plan, mode=0):
 
 
 @pytest.mark.parametrize("ext,mode", [([64, 64], 0), ([50, 50], 0), ([16, 16, 16], 0), ([8, 8, 8, 8], 0), ([5, 5, 5], 0),
-                                      ([4, 4, 4, 4, 4], 0), ([8191], 0), ([16, 16, 16], 2), ([64, 64], 2), ([90, 91], 0)])
+                                      ([4, 4, 4, 4, 4], 0), ([8191], 0), ([16, 16, 16], 2), ([64, 64], 2), ([90, 91], 0),
+                                      ([8193], 0), ([16384], 0), ([128, 128], 0), ([127, 129], 0), ([25, 25, 25], 0),
+                                      ([11, 11, 11, 11], 0), ([7, 7, 7, 7, 6], 0), ([128, 128], 2), ([16384], 2),
+                                      ([4, 4, 4, 4, 4, 4, 4], 2)])
 def test_single_workgroup_solver_matches_the_two_kernel_iteration(lib, monkeypatch, ext, mode):
-    """Grids of at most 8192 points run whole iterations inside one workgroup (csrc/cg_small.hpp);
+    """Grids of at most 16384 points run whole iterations inside one workgroup (csrc/cg_small.hpp: 8 points
+    per lane up to 8192 points, 16 beyond);
     CG_SMALL=0 sends the same solve through kernels A and B.  Same iteration count, histories and
     solutions to rounding; and the two kinds of launch can alternate on one solver."""
     N = int(np.prod(ext))
