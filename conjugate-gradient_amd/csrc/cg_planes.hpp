@@ -32,6 +32,11 @@ struct PlanesGeom
   // marching direction along axis 2 of kernels A and B (+1: ascending, -1: descending).  Opposite
   // directions let each kernel start where the other one stopped, on planes the Infinity Cache still holds.
   int dir_a, dir_b;
+  // nitems / 8 when work items are dealt to the XCDs in contiguous runs (0: item = tile index).  Workgroup b runs
+  // on XCD b % 8, so item i becomes tile (i % 8) * xcd_run + i / 8, tiles counted along axis 0 first, then axis 1,
+  // then the segments of axis 2: the workgroups resident on one XCD hold tiles that are neighbours along axes 0
+  // and 1, and the lines two tiles share (x edges, the rows just outside a tile) are fetched into that L2 once.
+  unsigned xcd_run;
 };
 
 constexpr int CG_PLANES_MAX_WAVES = 8;
@@ -93,10 +98,22 @@ __global__ void __launch_bounds__(512) k_planes(const PlanesGeom g, const VecArg
 
   for (unsigned item = blockIdx.x; item < g.nitems; item += gridDim.x)
   {
-    const unsigned zseg = item % g.nzs;
-    unsigned t = item / g.nzs;
-    const unsigned xc = t % g.nxc;
-    const unsigned yt = t / g.nxc;
+    unsigned zseg, xc, yt;
+    if (g.xcd_run)
+    {
+      unsigned t = (item & 7u) * g.xcd_run + (item >> 3);
+      xc = t % g.nxc;
+      t /= g.nxc;
+      yt = t % g.nyt;
+      zseg = t / g.nyt;
+    }
+    else
+    {
+      zseg = item % g.nzs;
+      const unsigned t = item / g.nzs;
+      xc = t % g.nxc;
+      yt = t / g.nxc;
+    }
     const long long z0 = (long long)((unsigned long long)zseg * g.n2 / g.nzs);
     const long long z1 = (long long)((unsigned long long)(zseg + 1) * g.n2 / g.nzs);
     if (z0 >= z1)

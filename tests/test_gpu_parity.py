@@ -689,6 +689,31 @@ def test_cache_policies_change_no_bit(lib, monkeypatch, ext, env):
     assert torch.equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("ext", [[512, 256, 64], [1024, 64, 40], [256, 128, 128], [260, 36, 24], [768, 48, 16]],
+                         ids=lambda e: "x".join(map(str, e)))
+def test_tiles_dealt_to_the_xcds_in_runs_give_the_same_solve(lib, monkeypatch, ext):
+    """The 3-D engine hands its tiles to the eight XCDs in contiguous runs when all of them are resident at once
+    (CG_PLANES_XCD, csrc/cg_planes.hpp); tile order only regroups the dot products' addends, so histories and x
+    agree with the plain order to rounding, and with the one-point-per-lane engine."""
+    N = int(np.prod(ext))
+    b = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(b.data_ptr(), N, 77)
+    out = []
+    for xcd, engine in (("0", 3), ("1", 3), ("1", 2)):
+        monkeypatch.setenv("CG_PLANES_XCD", xcd)
+        s = lib.make_solver(ext, engine=engine)
+        x = torch.zeros(N, dtype=torch.float32, device="cuda")
+        s.begin(b.data_ptr(), x.data_ptr(), 0.0, 1)
+        s.iterate(15)
+        iters, res, hist = s.finish(hist_len=15)
+        assert iters == 15
+        out.append((np.array(hist), x.cpu().numpy()))
+        s.close()
+    for h, xv in out[1:]:
+        assert np.allclose(h, out[0][0], rtol=1e-5)
+        assert rel_l2(xv, out[0][1]) <= 1e-5
+
+
 # ---- grids that fit one workgroup: whole iterations in a single launch -------------------------
 
 def _solve(lib, ext, b, plan, mode=0):
