@@ -144,6 +144,7 @@ struct RowsGeom
   unsigned nxc;    // columns per row of axis 0
   unsigned bpc;    // segments per column
   unsigned nitems; // columns * bpc
+  unsigned keep_y; // POL_PART: segments that end at or below this row keep r in the cache, the others stream it
   unsigned nk[CG_ROWS_MAXD];
   unsigned long long sk[CG_ROWS_MAXD];
   int has_lo, has_hi;
@@ -407,7 +408,11 @@ enum
   POL_KEEP_RP = 2,
   // everything streams, r included: for grids whose vectors exceed the cache several times over, where keeping
   // r resident buys nothing (rows engine only)
-  POL_STREAM = 3
+  POL_STREAM = 3,
+  // Vectors larger than the cache: a cyclic sweep over more bytes than the cache holds finds nothing of the last
+  // sweep in it, so only a cache-sized part of r is kept.  Work items of that part behave as under POL_KEEP_R,
+  // the others as under POL_STREAM (decided per work item, Src::ntr).
+  POL_PART = 4
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -452,11 +457,12 @@ struct Src
 {
   // p streams past the cache under POL_KEEP_R (in every mode but the plain stencil, whose
   // input is re-read by neighbouring rows of other workgroups); r is what the cache keeps
-  static constexpr bool NT_P = (POL == POL_KEEP_R || POL == POL_STREAM) && (MODE != MODE_STENCIL);
+  static constexpr bool NT_P = (POL == POL_KEEP_R || POL == POL_STREAM || POL == POL_PART) && (MODE != MODE_STENCIL);
   static constexpr bool NT_R = POL == POL_STREAM;
   const float *__restrict__ p;
   const float *__restrict__ r;
   float beta;
+  bool ntr = false; // POL_PART: this work item streams r
   __device__ __forceinline__ float ld1(long long i) const
   {
     float v = load1<NT_P>(p + i);
@@ -469,7 +475,7 @@ struct Src
     float4 v = load4<NT_P>(p + i);
     if constexpr (MODE == MODE_A)
     {
-      const float4 q = load4<NT_R>(r + i);
+      const float4 q = (POL == POL_PART && ntr) ? load4<true>(r + i) : load4<NT_R>(r + i);
       v.x = fmaf(beta, v.x, q.x);
       v.y = fmaf(beta, v.y, q.y);
       v.z = fmaf(beta, v.z, q.z);
@@ -518,7 +524,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
   static_assert(!PACK || D == 0 || D == 3, "packed rows exist for d >= 3 only");
   __shared__ double sh[16];
   const int tid = threadIdx.x, lane = tid & 63;
-  constexpr bool NT = POL == POL_KEEP_R || POL == POL_STREAM; // x, the stores of r and of p_new
+  constexpr bool NT = POL == POL_KEEP_R || POL == POL_STREAM || POL == POL_PART; // x, the stores of r and of p_new
   constexpr bool NT_R = POL == POL_STREAM;                     // kernel B's loads of r
   Src<MODE, POL> src;
   float *__restrict__ p_new = nullptr;
@@ -615,6 +621,8 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
     const long long y1 = (long long)((unsigned long long)(seg + 1) * g.n1 / g.bpc);
     if (y0 >= y1)
       continue;
+    const bool ntr = POL == POL_PART && y1 > (long long)g.keep_y;
+    src.ntr = ntr;
     const long long col0 = base + (x0 < g.n0 ? x0 : ((g.n0 + 3u) & ~3u) - 4u);
     const bool el = act && lane == 0 && x0 > 0;
     const bool er = act && lane == 63 && x0 + 4 < g.n0;
@@ -668,7 +676,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
         xv = load4<NT>(a.x + col0 + y0 * rs);
       if (xm == 2)
         qv = load4<Src<MODE, POL>::NT_P>(p_prev + col0 + y0 * rs);
-      rv = load4<NT_R>(a.r + col0 + y0 * rs);
+      rv = ntr ? load4<true>(a.r + col0 + y0 * rs) : load4<NT_R>(a.r + col0 + y0 * rs);
     }
     if constexpr (MODE == MODE_A)
     {
@@ -692,7 +700,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
             xn = load4<NT>(a.x + col0 + (y + 1) * rs);
           if (xm == 2)
             qn = load4<Src<MODE, POL>::NT_P>(p_prev + col0 + (y + 1) * rs);
-          rn = load4<NT_R>(a.r + col0 + (y + 1) * rs);
+          rn = ntr ? load4<true>(a.r + col0 + (y + 1) * rs) : load4<NT_R>(a.r + col0 + (y + 1) * rs);
         }
       }
 

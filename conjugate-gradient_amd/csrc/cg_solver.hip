@@ -283,6 +283,14 @@ static unsigned long long choose_segments(unsigned long long ncols, unsigned lon
   return segs;
 }
 
+// How much of r a solve keeps in the Infinity Cache (256 MiB on MI355X).  Measured on 2-D grids beyond the cache,
+// share of r kept against iterations/s: 16384 x 8192 (512 MiB per vector) 0 % 1330 (all of r streaming in kernel
+// A, all of it "kept" in B: nothing survives a sweep), 40 % 1404, 50 % 1444, 55 % 1422, 60 % 1408; 12288 x 8192
+// (384 MiB) 0 % 1540, 50 % 1722, 65 % 1778, 70 % 1672; 10240 x 8192 (320 MiB) 0 % 2105, 80 % 2400, 90 % 2064;
+// 16384^2 (1 GiB) 0 % 641, 25 % 670, 30 % 659: the best share is always the cache's size, and a little more
+// costs more than a little less.
+static unsigned long long keep_bytes() { return (unsigned long long)std::max(0, env_int("CG_KEEP_MB", 256)) << 20; }
+
 // columns x segments decomposition of the rows engine (see cg_device.hpp)
 static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, RowsGeom &g, int &block, int &grid,
                            unsigned s0 = 0, int per_cu = 0, bool for_kernel_a = false)
@@ -439,6 +447,8 @@ static void make_rows_geom(int d, const unsigned *n, int has_lo, int has_hi, Row
     g.xcd = 0; // the XCD of a work item is only known when items are whole columns
   g.has_lo = has_lo;
   g.has_hi = has_hi;
+  // POL_PART (1-D and 2-D): the rows whose r the Infinity Cache keeps
+  g.keep_y = (unsigned)std::min<unsigned long long>(keep_bytes() / ((unsigned long long)g.s0 * sizeof(float)), g.n1);
   grid = (int)std::min<unsigned long long>(items, std::min<unsigned long long>(target, (unsigned long long)max_blocks()));
 }
 
@@ -657,9 +667,11 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   CHECK(hipMemsetAsync(p0_base_, 0, buflen_ * sizeof(float), stream_));
   CHECK(hipMemsetAsync(p1_base_, 0, buflen_ * sizeof(float), stream_));
   build_geometry();
-  // Streaming hints: r stays in the 256 MiB Infinity Cache only if it fits, but in 1-D and 2-D the
-  // hints pay at any size (16384 x 8192: +2.6 %, 16384^2: even); the rows engine in d >= 3 re-reads
-  // p's far neighbours, which non-temporal loads would push back to HBM, so it uses plain accesses
+  // Streaming hints: r stays in the 256 MiB Infinity Cache -- all of it if it fits, a cache-sized part of it
+  // otherwise (POL_PART; 1-D and 2-D.  The 3-D engine gets the same effect from marching up in kernel A and down
+  // in kernel B: the half of r it touched last is the half it touches first, and keeping a fixed half instead
+  // measured no better).  The rows engine in d >= 3 re-reads p's far neighbours, which non-temporal loads would
+  // push back to HBM, so it uses plain accesses
   const bool keep_r = engine_ == ENGINE_PLANES || engine_ == ENGINE_MORTON4 || desc_.d <= 2;
   // paired x update (every engine's kernel B implements it)
   xdefer_ = env_int("CG_XDEFER", 1) != 0;
@@ -668,24 +680,25 @@ Solver::Solver(const SolverDesc &desc) : desc_(desc)
   // 20910 it/s, 4096^2 10870 -> 11680, 5120 x 4096 8530 -> 9120, 1-D 2^24 10740 -> 12070, 256^3 10770 -> 11340;
   // from 6144 x 4096 on (25 M points) keeping r wins (7470 against 6990; 320^3 4540 against 4010).
   const bool all_fit = N_ <= (21ull << 20) && engine_ != ENGINE_MORTON4;
-  policy_ = env_int("CG_CACHE_POLICY",
-                    all_fit ? POL_PLAIN : (engine_ == ENGINE_PLANES ? POL_KEEP_RP : (keep_r ? POL_KEEP_R : POL_PLAIN)));
-  if (policy_ == POL_KEEP_RP && engine_ != ENGINE_PLANES)
-    policy_ = POL_KEEP_R; // the third policy exists for the planes engine only
-  if (policy_ == POL_STREAM && engine_ != ENGINE_ROWS)
-    policy_ = POL_KEEP_R; // ... and the fourth for the rows engine
-  // Kernel A of the rows engine in 1-D and 2-D on grids whose vectors no longer fit the Infinity Cache (from
-  // 9/8 of its 256 MiB on) streams r as well: little of it survives until kernel B anyway, and the cache then
-  // serves kernel A's own stream better (kernel A: 9216 x 8192 195 -> 178 us, 10240 x 8192 234 -> 200, 16384 x
-  // 8192 316 -> 302, 16384^2 596 -> 573, 1-D 2^27 364 -> 328; 8192^2, which fits, loses: 130 -> 145; kernel B
-  // with the same policy loses 5 %, so it keeps r cached).  CG_CACHE_POLICY_A overrides.
-  policy_a_ = policy_;
-  if (engine_ == ENGINE_ROWS && desc_.d <= 2 && policy_ == POL_KEEP_R && N_ >= (1ull << 26) + (1ull << 23))
-    policy_a_ = POL_STREAM;
-  policy_a_ = env_int("CG_CACHE_POLICY_A", policy_a_);
-  if ((policy_a_ == POL_STREAM && engine_ != ENGINE_ROWS) || (policy_a_ == POL_KEEP_RP && engine_ != ENGINE_PLANES) ||
-      policy_a_ < POL_PLAIN || policy_a_ > POL_STREAM)
-    policy_a_ = policy_;
+  const bool part = engine_ == ENGINE_ROWS && desc_.d <= 2 && N_ * sizeof(float) > keep_bytes();
+  policy_ = env_int("CG_CACHE_POLICY", all_fit ? POL_PLAIN
+                                       : engine_ == ENGINE_PLANES ? POL_KEEP_RP
+                                       : part ? POL_PART
+                                       : keep_r ? POL_KEEP_R : POL_PLAIN);
+  // not every engine has every policy: the third exists for the planes engine, the fourth and fifth for the
+  // 1-D / 2-D rows
+  auto valid = [&](int pol) {
+    if (pol < POL_PLAIN || pol > POL_PART)
+      return (int)POL_KEEP_R;
+    if (pol == POL_KEEP_RP && engine_ != ENGINE_PLANES)
+      return (int)POL_KEEP_R;
+    if ((pol == POL_STREAM || pol == POL_PART) && !(engine_ == ENGINE_ROWS && desc_.d <= 2))
+      return (int)POL_KEEP_R;
+    return pol;
+  };
+  policy_ = valid(policy_);
+  // kernel A may take a policy of its own (CG_CACHE_POLICY_A); by default both kernels keep the same part of r
+  policy_a_ = valid(env_int("CG_CACHE_POLICY_A", policy_));
   sumA_ = partA_;
   sumB_ = partB_;
   nA_ = nB_ = grid_;
@@ -984,6 +997,12 @@ static void launch_rows(const RowsGeom &g, const VecArgs &a, int grid, int block
   else if (pol == POL_STREAM && MODE != MODE_STENCIL && !g.sub && g.d <= 2)
     launch_rows_pol<MODE, GHOST, POL_STREAM>(g, a, grid, block, s);
   else if (pol == POL_STREAM && MODE != MODE_STENCIL)
+    launch_rows_pol<MODE, GHOST, POL_KEEP_R>(g, a, grid, block, s);
+  else if (pol == POL_PART && MODE != MODE_STENCIL && !g.sub && g.d == 1)
+    hipLaunchKernelGGL((k_rows<MODE, GHOST, 1, POL_PART>), dim3(grid), dim3(block), 0, s, g, a);
+  else if (pol == POL_PART && MODE != MODE_STENCIL && !g.sub && g.d == 2)
+    hipLaunchKernelGGL((k_rows<MODE, GHOST, 2, POL_PART>), dim3(grid), dim3(block), 0, s, g, a);
+  else if (pol == POL_PART && MODE != MODE_STENCIL)
     launch_rows_pol<MODE, GHOST, POL_KEEP_R>(g, a, grid, block, s);
   else
     launch_rows_pol<MODE, GHOST, POL_PLAIN>(g, a, grid, block, s);

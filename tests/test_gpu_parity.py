@@ -664,11 +664,14 @@ def test_tiled_slots_of_blocked_columns_match_the_scalar_engine(lib, monkeypatch
 
 @pytest.mark.parametrize("ext", [[2048, 1024], [1 << 21], [1000, 700], [512, 64, 32], [64, 64, 64, 8]], ids=lambda e: "x".join(map(str, e)))
 @pytest.mark.parametrize("env", [{"CG_CACHE_POLICY": "0"}, {"CG_CACHE_POLICY": "1"}, {"CG_CACHE_POLICY": "3"},
-                                 {"CG_CACHE_POLICY_A": "3"}, {"CG_CACHE_POLICY": "2", "CG_CACHE_POLICY_A": "1"}],
+                                 {"CG_CACHE_POLICY_A": "3"}, {"CG_CACHE_POLICY": "2", "CG_CACHE_POLICY_A": "1"},
+                                 {"CG_CACHE_POLICY": "4", "CG_KEEP_MB": "3"}, {"CG_CACHE_POLICY": "4", "CG_KEEP_MB": "0"},
+                                 {"CG_CACHE_POLICY": "1", "CG_CACHE_POLICY_A": "4", "CG_KEEP_MB": "5"}],
                          ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()))
 def test_cache_policies_change_no_bit(lib, monkeypatch, ext, env):
-    """The cache policies (plain accesses, r kept in the Infinity Cache, r and p kept, everything streaming; one for
-    kernel A and one for kernel B) only choose between temporal and non-temporal loads and stores: a solve under
+    """The cache policies (plain accesses, r kept in the Infinity Cache, r and p kept, everything streaming, a
+    cache-sized part of r kept -- here 3 or 5 MiB of the 8 MiB vectors; one for kernel A and one for kernel B) only
+    choose between temporal and non-temporal loads and stores: a solve under
     any of them has the automatic choice's bits, whichever engine the grid takes (a policy that does not exist
     for that engine falls back)."""
     N = int(np.prod(ext))
