@@ -36,6 +36,7 @@
 //               registers, x-neighbours through cross-lane shifts.
 //   k_scalar -- one point per lane; any extent, any d, and the Morton layout.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -410,8 +411,8 @@ enum
   // r resident buys nothing (rows engine only)
   POL_STREAM = 3,
   // Vectors larger than the cache: a cyclic sweep over more bytes than the cache holds finds nothing of the last
-  // sweep in it, so only a cache-sized part of r is kept.  Work items of that part behave as under POL_KEEP_R,
-  // the others as under POL_STREAM (decided per work item, Src::ntr).
+  // sweep in it, so only a cache-sized part of r is kept.  Work items of that part run under POL_KEEP_R, the
+  // others under POL_STREAM (1-D and 2-D rows).
   POL_PART = 4
 };
 
@@ -457,12 +458,11 @@ struct Src
 {
   // p streams past the cache under POL_KEEP_R (in every mode but the plain stencil, whose
   // input is re-read by neighbouring rows of other workgroups); r is what the cache keeps
-  static constexpr bool NT_P = (POL == POL_KEEP_R || POL == POL_STREAM || POL == POL_PART) && (MODE != MODE_STENCIL);
+  static constexpr bool NT_P = (POL == POL_KEEP_R || POL == POL_STREAM) && (MODE != MODE_STENCIL);
   static constexpr bool NT_R = POL == POL_STREAM;
   const float *__restrict__ p;
   const float *__restrict__ r;
   float beta;
-  bool ntr = false; // POL_PART: this work item streams r
   __device__ __forceinline__ float ld1(long long i) const
   {
     float v = load1<NT_P>(p + i);
@@ -475,7 +475,7 @@ struct Src
     float4 v = load4<NT_P>(p + i);
     if constexpr (MODE == MODE_A)
     {
-      const float4 q = (POL == POL_PART && ntr) ? load4<true>(r + i) : load4<NT_R>(r + i);
+      const float4 q = load4<NT_R>(r + i);
       v.x = fmaf(beta, v.x, q.x);
       v.y = fmaf(beta, v.y, q.y);
       v.z = fmaf(beta, v.z, q.z);
@@ -524,9 +524,8 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
   static_assert(!PACK || D == 0 || D == 3, "packed rows exist for d >= 3 only");
   __shared__ double sh[16];
   const int tid = threadIdx.x, lane = tid & 63;
-  constexpr bool NT = POL == POL_KEEP_R || POL == POL_STREAM || POL == POL_PART; // x, the stores of r and of p_new
-  constexpr bool NT_R = POL == POL_STREAM;                     // kernel B's loads of r
-  Src<MODE, POL> src;
+  // pointers and beta of the stencil input; a work item loads through Src<MODE, its own policy>
+  Src<MODE, POL_PLAIN> src0;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
   // paired x update (kernel B): xm and the p of the previous iteration
@@ -538,17 +537,17 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
     const IterCtl c = prologue_A(a, sh);
     if (!c.active)
       return;
-    src.p = (c.k & 1) ? a.p1 : a.p0;
+    src0.p = (c.k & 1) ? a.p1 : a.p0;
     p_new = (c.k & 1) ? a.p0 : a.p1;
-    src.r = a.r;
-    src.beta = c.coef;
+    src0.r = a.r;
+    src0.beta = c.coef;
   }
   else if constexpr (MODE == MODE_B)
   {
     const IterCtl c = prologue_B<true>(a, sh);
     if (!c.active)
       return;
-    src.p = (c.k & 1) ? a.p0 : a.p1;
+    src0.p = (c.k & 1) ? a.p0 : a.p1;
     p_prev = (c.k & 1) ? a.p1 : a.p0;
     coef = c.coef;
     xm = c.xm;
@@ -556,7 +555,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
   }
   else
   {
-    src.p = a.u;
+    src0.p = a.u;
   }
   const float alpha = coef;
   float acc = 0;
@@ -575,8 +574,15 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
   // packed columns march along the last axis, so (as in 2-D) the ghosted axis is the marching one
   const bool rowghost = GHOST && (PACK || d == 2);
 
-  for (unsigned item = blockIdx.x; item < g.nitems; item += gridDim.x)
-  {
+  // one work item under cache policy P (POL itself, or under POL_PART the policy of the item's part of the grid)
+  auto work = [&](auto pol_c, const unsigned item) {
+    constexpr int P = decltype(pol_c)::value;
+    constexpr bool NT = P == POL_KEEP_R || P == POL_STREAM; // x, the stores of r and of p_new
+    constexpr bool NT_R = P == POL_STREAM;                  // kernel B's loads of r
+    Src<MODE, P> src;
+    src.p = src0.p;
+    src.r = src0.r;
+    src.beta = src0.beta;
     const unsigned seg = item % g.bpc;
     const unsigned col = item / g.bpc;
     unsigned xc = 0, hi, x0;
@@ -620,9 +626,7 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
     const long long y0 = (long long)((unsigned long long)seg * g.n1 / g.bpc);
     const long long y1 = (long long)((unsigned long long)(seg + 1) * g.n1 / g.bpc);
     if (y0 >= y1)
-      continue;
-    const bool ntr = POL == POL_PART && y1 > (long long)g.keep_y;
-    src.ntr = ntr;
+      return;
     const long long col0 = base + (x0 < g.n0 ? x0 : ((g.n0 + 3u) & ~3u) - 4u);
     const bool el = act && lane == 0 && x0 > 0;
     const bool er = act && lane == 63 && x0 + 4 < g.n0;
@@ -675,8 +679,8 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
       if (xm != 1)
         xv = load4<NT>(a.x + col0 + y0 * rs);
       if (xm == 2)
-        qv = load4<Src<MODE, POL>::NT_P>(p_prev + col0 + y0 * rs);
-      rv = ntr ? load4<true>(a.r + col0 + y0 * rs) : load4<NT_R>(a.r + col0 + y0 * rs);
+        qv = load4<Src<MODE, P>::NT_P>(p_prev + col0 + y0 * rs);
+      rv = load4<NT_R>(a.r + col0 + y0 * rs);
     }
     if constexpr (MODE == MODE_A)
     {
@@ -699,8 +703,8 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
           if (xm != 1)
             xn = load4<NT>(a.x + col0 + (y + 1) * rs);
           if (xm == 2)
-            qn = load4<Src<MODE, POL>::NT_P>(p_prev + col0 + (y + 1) * rs);
-          rn = ntr ? load4<true>(a.r + col0 + (y + 1) * rs) : load4<NT_R>(a.r + col0 + (y + 1) * rs);
+            qn = load4<Src<MODE, P>::NT_P>(p_prev + col0 + (y + 1) * rs);
+          rn = load4<NT_R>(a.r + col0 + (y + 1) * rs);
         }
       }
 
@@ -821,11 +825,12 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
             }
             else if (d >= 3)
             {
-              const long long s = (long long)g.sk[d - 3];
+              const int kl = d >= 3 ? d - 3 : 0; // (d < 3 never gets here)
+              const long long s = (long long)g.sk[kl];
               if (push_lo && st_lo)
                 store4<false>(push_lo + idx, rv);
               if (push_hi && st_hi)
-                store4<false>(push_hi + (idx - (long long)(g.nk[d - 3] - 1u) * s), rv);
+                store4<false>(push_hi + (idx - (long long)(g.nk[kl] - 1u) * s), rv);
             }
           }
         }
@@ -851,6 +856,20 @@ __global__ void __launch_bounds__(PACK ? 1024 : 256) k_rows( // packed columns: 
       if (rowghost && g.has_hi && y1 == n1 && act)
         store4<NT>(p_new + col0 + y1 * rs, pc);
     }
+  };
+  for (unsigned item = blockIdx.x; item < g.nitems; item += gridDim.x)
+  {
+    if constexpr (POL == POL_PART)
+    {
+      // a work item takes the policy of the part of the grid in which its last row lies
+      const unsigned long long y1 = (unsigned long long)(item % g.bpc + 1u) * g.n1 / g.bpc;
+      if (y1 <= g.keep_y)
+        work(std::integral_constant<int, POL_KEEP_R>{}, item);
+      else
+        work(std::integral_constant<int, POL_STREAM>{}, item);
+    }
+    else
+      work(std::integral_constant<int, POL>{}, item);
   }
   if constexpr (MODE != MODE_STENCIL)
     block_write_partial(acc, a, sh);
