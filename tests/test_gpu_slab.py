@@ -134,6 +134,23 @@ def test_boundary_planes_computed_ahead_of_kernel_B_are_its_bits(pkg, lib, engin
     assert np.array_equal(x0, x1)
 
 
+@pytest.mark.parametrize("L,nranks,keep_mb", [(1024, 2, "1"), (1024, 4, "0"), (512, 2, "1")])
+def test_slabs_that_keep_only_part_of_r_in_the_cache_change_no_bit(pkg, lib, monkeypatch, L, nranks, keep_mb):
+    """2-D slabs larger than the cache budget (CG_KEEP_MB, shrunk here so that small slabs qualify) keep only their
+    first rows of r in the Infinity Cache and stream the rest: the same solve bit for bit, ghost rows and the
+    planes pushed to the neighbours included."""
+    N = L * L
+    bd = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.c.cg_fill_uniform(bd.data_ptr(), N, 5)
+    b = bd.cpu().numpy()
+    x0, it0, h0 = run_virtual(pkg, lib, L, 2, nranks, b, 30, ahead=True)
+    monkeypatch.setenv("CG_KEEP_MB", keep_mb)
+    monkeypatch.setenv("CG_CACHE_POLICY", "4")
+    x1, it1, h1 = run_virtual(pkg, lib, L, 2, nranks, b, 30, ahead=True)
+    assert it0 == it1 and h0 == h1
+    assert np.array_equal(x0, x1)
+
+
 @pytest.mark.parametrize("L,d,heights", [(16, 3, [6, 10]), (64, 2, [10, 30, 24]), (32, 3, [4, 20, 8])])
 def test_virtual_ranks_of_unequal_height(pkg, lib, oracle, engine_env, L, d, heights):
     """Slabs of different heights launch different numbers of workgroups, so their arrays of partial sums
