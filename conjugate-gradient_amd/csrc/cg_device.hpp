@@ -92,6 +92,11 @@ struct CgState
   int xdef_k;       // last iteration whose x update was left out (-2: none)
   int xflushed_at;  // iteration count at which a flush applied a pending update (-1: never)
   float alpha_hist[2];
+  // r.r of the last two iterations, rr_pp[k & 1] = r.r entering iteration k: the copy of rr_hist's newest two
+  // entries that the prologues read.  Both slots are loaded unconditionally together with everything else the
+  // prologue needs (one trip to memory) and selected once the iteration number has arrived; an address that
+  // depends on it (rr_hist[k % CG_HIST]) would cost a second trip, about 0.6 us per kernel.
+  float rr_pp[2];
   float rr_hist[CG_HIST];
 };
 
@@ -325,16 +330,20 @@ struct IterCtl
 __device__ __forceinline__ IterCtl prologue_A(const VecArgs &a, double *sh)
 {
   CgState *st = a.st;
+  // everything the state has to say is requested before the partial sums are, so that it all travels together
   const int k = st->itA;
   const int done = st->doneA;
+  const int lagged = st->lagged, maxit = st->maxit;
+  const float reltol = st->reltol;
+  const float rr_p0 = st->rr_pp[0], rr_p1 = st->rr_pp[1];
   const float rr = (CG_DBG & 4) ? 1.0f : (float)block_read_sum(a.sumB, a.nB, sh);
-  const float rr_prev = st->rr_hist[(k + CG_HIST - 1) % CG_HIST];
-  const float rr_test = (st->lagged && k > 0) ? rr_prev : rr;
+  const float rr_prev = (k & 1) ? rr_p0 : rr_p1; // rr_pp[(k - 1) & 1]
+  const float rr_test = (lagged && k > 0) ? rr_prev : rr;
   const float residue = (float)sqrt((double)rr_test);
-  const bool conv = done || !(residue > st->reltol);
+  const bool conv = done || !(residue > reltol);
   IterCtl c;
   c.k = k;
-  c.active = !conv && k < st->maxit;
+  c.active = !conv && k < maxit;
   c.coef = k > 0 ? rr / rr_prev : 0.0f;
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
@@ -342,6 +351,7 @@ __device__ __forceinline__ IterCtl prologue_A(const VecArgs &a, double *sh)
     st->doneB = conv;
     st->activeB = c.active;
     st->rr_hist[k % CG_HIST] = rr;
+    st->rr_pp[k & 1] = rr;
     st->beta = c.coef;
   }
   return c;
@@ -353,11 +363,15 @@ __device__ __forceinline__ IterCtl prologue_B(const VecArgs &a, double *sh)
 {
   CgState *st = a.st;
   IterCtl c;
+  // as in prologue_A: all of the state in flight before the partial sums
   c.k = st->itB;
   c.active = st->activeB != 0;
   const int done = st->doneB;
+  const float rr_p0 = st->rr_pp[0], rr_p1 = st->rr_pp[1];
+  const int xdef_k = XD ? st->xdef_k : 0, xflushed_at = XD ? st->xflushed_at : 0;
+  const float ah0 = XD ? st->alpha_hist[0] : 0.0f, ah1 = XD ? st->alpha_hist[1] : 0.0f;
   const float pAp = (CG_DBG & 4) ? 1e9f : (float)block_read_sum(a.sumA, a.nA, sh);
-  c.coef = st->rr_hist[c.k % CG_HIST] / pAp;
+  c.coef = ((c.k & 1) ? rr_p1 : rr_p0) / pAp; // rr_pp[k & 1], what prologue_A of this iteration stored
   c.xm = 0;
   c.alpha_prev = 0.0f;
   if constexpr (XD)
@@ -365,10 +379,10 @@ __device__ __forceinline__ IterCtl prologue_B(const VecArgs &a, double *sh)
     // a launch that may leave x alone only writes xdef_k, every other launch only reads it
     if (a.xdefer)
       c.xm = 1;
-    else if (st->xdef_k == c.k - 1 && st->xflushed_at != c.k)
+    else if (xdef_k == c.k - 1 && xflushed_at != c.k)
     {
       c.xm = 2;
-      c.alpha_prev = st->alpha_hist[(c.k - 1) & 1];
+      c.alpha_prev = ((c.k - 1) & 1) ? ah1 : ah0;
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)

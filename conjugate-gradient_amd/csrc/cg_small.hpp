@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(CG_SMALL_THREADS) k_small(const SmallGeom g, c
     if (tid == 0)
     {
       st->rr_hist[k % CG_HIST] = rr;
+      st->rr_pp[k & 1] = rr;
       st->beta = beta;
     }
     done = conv;

@@ -98,6 +98,8 @@ __global__ void __launch_bounds__(64) k_init_state(CgState *st, const double *__
     st->xflushed_at = -1;
     st->alpha_hist[0] = st->alpha_hist[1] = 0;
     st->rr_hist[0] = rr;
+    st->rr_pp[0] = rr;
+    st->rr_pp[1] = 0;
   }
 }
 
