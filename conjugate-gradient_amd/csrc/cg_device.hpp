@@ -50,6 +50,23 @@ namespace cgamd
 #ifndef CG_DBG
 #define CG_DBG 0
 #endif
+// -DCG_DBG=64: the one-point-per-lane kernels of the first and the last workgroup leave time stamps (100 MHz
+// clock, after waiting for their outstanding memory operations) at entry, after the prologue, after the body and
+// at the end; cg_dbg_times() copies them out (tools/dbg/ktimes.py).  Not compiled otherwise.
+#if CG_DBG & 64
+__device__ unsigned long long cg_dbg_t[64];
+#define CG_T(i)                                                                                          \
+  do                                                                                                     \
+  {                                                                                                      \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                            \
+    {                                                                                                    \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+      cg_dbg_t[(i) + (blockIdx.x == 0 ? 0 : 16) + (MODE == MODE_B ? 32 : 0)] = wall_clock64();           \
+    }                                                                                                    \
+  } while (0)
+#else
+#define CG_T(i)
+#endif
 
 constexpr int CG_MAXD = 32;        // scalar engine
 constexpr int CG_ROWS_MAXD = 14;   // rows engine: axes 2..15 (rows of >= 4 points and N < 2^32 allow no more)
@@ -895,6 +912,7 @@ template <int MODE, bool GHOST, int LAYOUT>
 __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArgs a)
 {
   __shared__ double sh[8];
+  CG_T(0);
   Src<MODE, POL_PLAIN> src;
   float *__restrict__ p_new = nullptr;
   float coef = 0;
@@ -928,6 +946,7 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
   }
   const float alpha = coef;
   float acc = 0;
+  CG_T(1);
   float *push_lo = nullptr, *push_hi = nullptr;
   if constexpr (MODE == MODE_B && GHOST)
     push_targets(a, push_lo, push_hi);
@@ -1014,8 +1033,10 @@ __global__ void __launch_bounds__(256) k_scalar(const ScalarGeom g, const VecArg
       acc = fmaf(rv, rv, acc);
     }
   }
+  CG_T(2);
   if constexpr (MODE != MODE_STENCIL)
     block_write_partial(acc, a, sh);
+  CG_T(3);
 }
 
 // ---- small kernels (defined in cg_solver.hip) ------------------------------------------

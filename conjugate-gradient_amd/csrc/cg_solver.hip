@@ -1961,3 +1961,12 @@ void fill_uniform(float *dst, unsigned long long n, unsigned int seed, hipStream
 }
 
 } // namespace cgamd
+
+#if CG_DBG & 64
+// the time stamps of a -DCG_DBG=64 build (cg_device.hpp, CG_T)
+extern "C" void cg_dbg_times(unsigned long long *out)
+{
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgamd::cg_dbg_t), 64 * sizeof(unsigned long long));
+}
+#endif
